@@ -1,0 +1,113 @@
+/* oracle_solve.c -- output-time loop, error policy and cell hand-off.  TEST INFRASTRUCTURE ONLY.
+ * Restates src/chemistry.f90:391-588 chem_evol_solve and :272-387 ode_solver_error_handling for the
+ * fixed-T mode (evolT = maySwitchT = .false., update_gH_params_realtime = .false.), plus the cell
+ * initial condition of src/disk.f90:2055-2066 and the call order of src/disk.f90:1671-1686.
+ * The reference's CPU-time guards (:480-491) are non-deterministic and are not restated; with the
+ * template's max_runtime_allowed = 60 s they do not fire on any fixture cell.
+ */
+#include "oracle.h"
+#include "oracle_lsodes.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { const orc_network *net; const orc_params *p; const double *cell, *rates; const orc_symbolic *S; } cb_ctx;
+static void cb_f(void *c, const double *y, double *ydot) { cb_ctx *x = c; orc_ode_f(x->net, x->p, x->cell, x->rates, y, ydot); }
+static void cb_jac(void *c, const double *y, double *vals) {
+  cb_ctx *x = c; orc_jac_on_pattern(x->net, x->p, x->cell, x->rates, y, x->S->IAN, x->S->JAN, vals);
+}
+
+/* The symbolic factorisation is cell independent: cache one per network (not thread safe by design). */
+static const orc_network *g_net; static orc_symbolic *g_sym;
+static const orc_symbolic *symbolic_for(const orc_network *net) {
+  if (g_net != net) { orc_symbolic_free(g_sym); g_sym = orc_symbolic_build(net->NEQ, net->IA, net->JA); g_net = net; }
+  return g_sym;
+}
+
+/* ode_solver_error_handling: only the tolerance loosening has an effect on the computation */
+static void loosen(const orc_network *net, int istate, int imxer, double *rtol, double *atol) {
+  if (istate != -4 && istate != -5) return;
+  int idx = imxer - 1;
+  if (imxer <= net->nS) { rtol[idx] = fmin(rtol[idx] * 10.0, 1e-3); atol[idx] = fmin(atol[idx] * 100.0, 1e-20); }
+  else { rtol[idx] = fmin(rtol[idx] * 10.0, 1e-2); atol[idx] = fmin(atol[idx] * 100.0, 1.0); }
+}
+
+int orc_evol_solve(const orc_network *net, const orc_params *p, const double *cell, const double *rates,
+                   double *rtol, double *atol, double *y, double t0, double t_max,
+                   double *t_final, int *quality, int *nerr_out, int *n_record_real,
+                   double *record, double *touts, orc_stats *st) {
+  const int NEQ = net->NEQ;
+  const orc_symbolic *S = symbolic_for(net);
+  cb_ctx ctx = {net, p, cell, rates, S};
+  orc_lsodes *s = orc_lsodes_create(NEQ, S, cb_f, cb_jac, &ctx);
+  s->rtol = rtol; s->atol = atol; s->tcrit = t_max; s->hmax = t_max; s->mxstep = p->mxstep_per_interval;
+  int n_record = orc_n_record(p, t0, t_max);
+  int istate = 1, nerr = 0, nerr_c = 0, qual = 0, nrr = 1, ret = 0;
+  double t = t0, t_step = p->dt_first_step, tout = t + t_step;
+  orc_stats acc; memset(&acc, 0, sizeof acc);
+  if (touts) touts[0] = t;
+  if (record) memcpy(record, y, (size_t)NEQ * sizeof(double));
+  for (int i = 2; i <= n_record; i++) {
+    if (tout >= t_max) tout = t_max;
+    int was_restart = (istate == 1);
+    long nst0 = was_restart ? 0 : s->nst, nfe0 = was_restart ? 0 : s->nfe, nje0 = was_restart ? 0 : s->nje, nlu0 = was_restart ? 0 : s->nlu;
+    orc_lsodes_call(s, y, &t, tout, &istate);
+    acc.nst += s->nst - nst0; acc.nfe += s->nfe - nfe0; acc.nje += s->nje - nje0; acc.nlu += s->nlu - nlu0;
+    if (touts) touts[i - 1] = t;
+    if (record) memcpy(record + (size_t)(i - 1) * NEQ, y, (size_t)NEQ * sizeof(double));
+    nrr = i;
+    if (t >= t_max) break;
+    if (istate < 0) {
+      nerr++; nerr_c++;
+      if (istate == -7) { ret = -7; break; } /* error_stop */
+      loosen(net, istate, s->imxer, rtol, atol);
+      if (istate == -3) { qual += 256; break; }
+      if (nerr_c < 3) istate = 3; else { istate = 1; nerr_c = 0; }
+    }
+    {
+      double yT = y[NEQ - 1]; int bad = isnan(yT) || yT <= 0.0;
+      /* the reference indexes y(i_gH2) etc. even when the index is 0; only meaningful when present */
+      if (net->i_gH2 > 0 && fabs(y[net->i_gH2 - 1]) > 1.0) bad = 1;
+      if (net->i_gH2O > 0 && fabs(y[net->i_gH2O - 1]) > 1.0) bad = 1;
+      if (net->i_gH > 0 && fabs(y[net->i_gH - 1]) > 1.0) bad = 1;
+      if (net->idx10[1] > 0 && fabs(y[net->idx10[1] - 1]) > 2.0) bad = 1;
+      if (net->idx10[2] > 0 && fabs(y[net->idx10[2] - 1]) > 1.0) bad = 1;
+      if (bad) { qual += 512; break; }
+    }
+    if (p->steps_reset_solver > 0 && i % p->steps_reset_solver == 0) istate = 1;
+    t_step = t_step * p->ratio_tstep;
+    tout = t + t_step;
+  }
+  for (int i = nrr + 1; i <= n_record; i++) {
+    if (touts) touts[i - 1] = t;
+    if (record) memcpy(record + (size_t)(i - 1) * NEQ, y, (size_t)NEQ * sizeof(double));
+  }
+  if (nerr > (int)(0.1f * (float)n_record)) qual += 1;
+  if (t <= 0.5 * t_max) qual += 2;
+  if (t_final) *t_final = t;
+  if (quality) *quality = qual;
+  if (nerr_out) *nerr_out = nerr;
+  if (n_record_real) *n_record_real = nrr;
+  if (st) {
+    *st = acc; st->nnz = S->nnz; st->nzl = S->nzl; st->nzu = S->nzu;
+    st->nst_last = s->nst; st->nfe_last = s->nfe; st->nje_last = s->nje; st->nlu_last = s->nlu;
+  }
+  orc_lsodes_free(s);
+  return ret;
+}
+
+int orc_solve_cell(const orc_network *net, const orc_params *p, const double *cell, const double *y0,
+                   double *y_out, double *t_final, int *quality, int *nerr, orc_stats *stats) {
+  const int NEQ = net->NEQ, nS = net->nS;
+  double *rates = malloc((size_t)net->nR * sizeof(double));
+  double *rtol = malloc((size_t)NEQ * sizeof(double)), *atol = malloc((size_t)NEQ * sizeof(double));
+  memcpy(y_out, y0, (size_t)nS * sizeof(double));
+  if (net->i_Grain0 > 0) y_out[net->i_Grain0 - 1] = cell[ORC_P_D2H];
+  y_out[nS] = cell[ORC_P_TGAS];
+  double t_max = cell[ORC_P_TMAX] > 0.0 ? cell[ORC_P_TMAX] : p->t_max;
+  orc_set_tolerances(net, p, 1, cell[ORC_P_D2H], rtol, atol);
+  int rc = orc_cal_rates(net, p, cell, rates, NULL);
+  if (rc == 0) rc = orc_evol_solve(net, p, cell, rates, rtol, atol, y_out, 0.0, t_max, t_final, quality, nerr, NULL, NULL, NULL, stats);
+  free(rates); free(rtol); free(atol);
+  return rc;
+}

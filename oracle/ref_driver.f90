@@ -1,0 +1,232 @@
+! ref_driver.f90 -- TEST INFRASTRUCTURE ONLY (oracle/_ref).
+!
+! A driver of our own that links against the UNMODIFIED reference objects (everything except its
+! main program) and calls only the reference's routines, following the single-cell fixed-T recipe
+! of SURVEY.md section 8(c) (reference: src/disk.f90:1566-1581 setup sequence, src/disk.f90:2014-2100
+! initial condition, src/chemistry.f90:391 chem_evol_solve).  It exists to (1) validate the C
+! restatement in oracle/ and (2) generate the golden vectors committed under tests/golden/.
+! It is never part of the product path and never travels as source to the GPU box.
+!
+! Input : a namelist file (argument 1) + a whitespace-separated cell table (one cell per row,
+!         28 columns = the racgpu cell record, see include/racgpu.h).
+! Output: plain-text vectors, one value per line, %ES25.17E3.
+program ref_driver
+  use chemistry
+  implicit none
+  external chem_ode_f, chem_ode_jac
+  character(len=256) :: nml_file, chem_dir, network, initial, out_dir, cell_file
+  integer :: ncell, mxstep, steps_reset, dump_jac, dump_record_every, solve
+  double precision :: rtol, atol, dt_first_step, ratio_tstep, t_max
+  logical :: h2_moeq
+  namelist /ref_run/ chem_dir, network, initial, out_dir, cell_file, ncell, &
+    rtol, atol, dt_first_step, ratio_tstep, t_max, mxstep, steps_reset, h2_moeq, &
+    dump_jac, dump_record_every, solve
+  integer, parameter :: NPAR = 28
+  double precision :: cpar(NPAR)
+  double precision, allocatable :: ydot(:), pdj(:), dummy(:)
+  integer :: ic, i, j, k, fU, fC, NEQ, nS, c0, c1, crate
+  character(len=300) :: fname
+  double precision :: tdummy
+
+  call get_command_argument(1, nml_file)
+  chem_dir = './'; network = ''; initial = ''; out_dir = './'; cell_file = ''
+  ncell = 1; rtol = 1D-4; atol = 1D-30; dt_first_step = 1D-8; ratio_tstep = 1.1D0
+  t_max = 1D6; mxstep = 6000; steps_reset = 50; h2_moeq = .false.
+  dump_jac = 1; dump_record_every = 0; solve = 1
+  open(newunit=fU, file=trim(nml_file), status='old', action='read')
+  read(fU, nml=ref_run)
+  close(fU)
+
+  chemsol_params%chem_files_dir = chem_dir
+  chemsol_params%filename_chemical_network = network
+  chemsol_params%filename_initial_abundances = initial
+  chemsol_params%filename_species_enthalpy = ''
+  chemsol_params%RTOL = rtol
+  chemsol_params%ATOL = atol
+  chemsol_params%t0 = 0D0
+  chemsol_params%t_max = t_max
+  chemsol_params%dt_first_step = dt_first_step
+  chemsol_params%ratio_tstep = ratio_tstep
+  chemsol_params%max_runtime_allowed = 1.0E9
+  chemsol_params%mxstep_per_interval = mxstep
+  chemsol_params%steps_reset_solver = steps_reset
+  chemsol_params%H2_form_use_moeq = h2_moeq
+  chemsol_params%flag_chem_evol_save = .false.
+  chemsol_params%evol_dust_size = .false.
+  open(newunit=fU, file=trim(out_dir)//'/ref_log.txt', status='replace', action='write')
+  chemsol_params%fU_log = fU
+
+  ! The reference's own setup sequence (src/disk.f90:1566-1581, minus enthalpies).
+  call chem_read_reactions()
+  call chem_load_reactions()
+  call chem_parse_reactions()
+  call chem_get_dupli_reactions()
+  call chem_get_idx_for_special_species()
+  call chem_make_sparse_structure
+  call chem_prepare_solver_storage
+  call chem_evol_solve_prepare_run_once
+  call chem_load_initial_abundances
+
+  nS = chem_species%nSpecies
+  NEQ = chemsol_params%NEQ
+  allocate(ydot(NEQ), pdj(NEQ), dummy(1))
+
+  ! ---- network-level dumps -------------------------------------------------
+  open(newunit=fC, file=trim(out_dir)//'/species.txt', status='replace')
+  do i = 1, nS
+    write(fC, '(A)') trim(chem_species%names(i))
+  end do
+  close(fC)
+  open(newunit=fC, file=trim(out_dir)//'/network.txt', status='replace')
+  write(fC, '(3I8)') nS, chem_net%nReactions, chemsol_params%NNZ
+  do i = 1, chem_net%nReactions
+    write(fC, '(11I6)') chem_net%reac(:, i), chem_net%prod(:, i), chem_net%n_reac(i), &
+      chem_net%n_prod(i), chem_net%itype(i), chem_net%dupli(i)%nItem
+  end do
+  close(fC)
+  open(newunit=fC, file=trim(out_dir)//'/species_attr.txt', status='replace')
+  do i = 1, nS
+    write(fC, '(3ES25.17E3, I8, I4)') chem_species%mass_num(i), chem_species%vib_freq(i), &
+      chem_species%Edesorb(i), chem_species%idx_gasgrain_counterpart(i), chem_species%elements(1, i)
+  end do
+  close(fC)
+  open(newunit=fC, file=trim(out_dir)//'/pattern.txt', status='replace')
+  do i = 1, NEQ + 1
+    write(fC, '(I8)') chemsol_stor%IWORK(30 + i)
+  end do
+  do i = 1, chemsol_params%NNZ
+    write(fC, '(I8)') chemsol_stor%IWORK(31 + NEQ + i)
+  end do
+  close(fC)
+  open(newunit=fC, file=trim(out_dir)//'/y0.txt', status='replace')
+  do i = 1, nS
+    write(fC, '(ES25.17E3)') chemsol_stor%y0(i)
+  end do
+  close(fC)
+
+  open(newunit=fU, file=trim(cell_file), status='old', action='read')
+  do ic = 1, ncell
+    read(fU, *) cpar
+    chem_params%Tgas                      = cpar(1)
+    chem_params%Tdust                     = cpar(2)
+    chem_params%n_gas                     = cpar(3)
+    chem_params%GrainRadius_CGS           = cpar(4)
+    chem_params%sigdust_ave               = cpar(5)
+    chem_params%ndust_tot                 = cpar(6)
+    chem_params%ratioDust2HnucNum         = cpar(7)
+    chem_params%SitesPerGrain             = cpar(8)
+    chem_params%omega_albedo              = cpar(9)
+    chem_params%zeta_cosmicray_H2         = cpar(10)
+    chem_params%zeta_Xray_H2              = cpar(11)
+    chem_params%Ncol_toISM                = cpar(12)
+    chem_params%Av_toISM                  = cpar(13)
+    chem_params%Av_toStar                 = cpar(14)
+    chem_params%G0_UV_toISM               = cpar(15)
+    chem_params%G0_UV_toStar              = cpar(16)
+    chem_params%G0_UV_H2phd               = cpar(17)
+    chem_params%G0_UV_toStar_photoDesorb  = cpar(18)
+    chem_params%phflux_Lya                = cpar(19)
+    chem_params%f_selfshielding_toISM_H2  = cpar(20)
+    chem_params%f_selfshielding_toISM_CO  = cpar(21)
+    chem_params%f_selfshielding_toISM_H2O = cpar(22)
+    chem_params%f_selfshielding_toISM_OH  = cpar(23)
+    chem_params%f_selfshielding_toStar_H2 = cpar(24)
+    chem_params%f_selfshielding_toStar_CO = cpar(25)
+    chem_params%f_selfshielding_toStar_H2O= cpar(26)
+    chem_params%f_selfshielding_toStar_OH = cpar(27)
+
+    ! src/disk.f90:2055-2075 (set_initial_condition_4solver), fixed-T branch.
+    chemsol_stor%y(1:nS) = chemsol_stor%y0(1:nS)
+    if (chem_idx_some_spe%i_Grain0 .ne. 0) then
+      chemsol_stor%y(chem_idx_some_spe%i_Grain0) = chem_params%ratioDust2HnucNum
+    end if
+    chemsol_stor%y(nS + 1) = chem_params%Tgas
+    chemsol_params%evolT = .false.
+    chemsol_params%maySwitchT = .false.
+    chemsol_params%t0 = 0D0
+    chemsol_params%dt_first_step = dt_first_step
+    chemsol_params%t_max = t_max
+    if (cpar(28) .gt. 0D0) chemsol_params%t_max = cpar(28)
+    call chem_evol_solve_prepare_ongoing
+    ! src/disk.f90:1671-1686 order: flags, rates, solve.
+    call chem_set_solver_flags_alt(1)
+    call chem_cal_rates
+
+    write(fname, '(A, "/cell_", I4.4, ".txt")') trim(out_dir), ic
+    open(newunit=fC, file=trim(fname), status='replace')
+    write(fC, '(A, I8)') '# rates ', chem_net%nReactions
+    do i = 1, chem_net%nReactions
+      write(fC, '(ES25.17E3)') chem_net%rates(i)
+    end do
+    write(fC, '(A, I8)') '# rtol ', NEQ
+    do i = 1, NEQ
+      write(fC, '(ES25.17E3)') chemsol_stor%RTOLs(i)
+    end do
+    write(fC, '(A, I8)') '# atol ', NEQ
+    do i = 1, NEQ
+      write(fC, '(ES25.17E3)') chemsol_stor%ATOLs(i)
+    end do
+    tdummy = 0D0
+    call chem_ode_f(NEQ, tdummy, chemsol_stor%y, ydot)
+    write(fC, '(A, I8)') '# ydot0 ', NEQ
+    do i = 1, NEQ
+      write(fC, '(ES25.17E3)') ydot(i)
+    end do
+    if (dump_jac .ne. 0) then
+      write(fC, '(A, I8)') '# jac0 ', chemsol_params%NNZ
+      do j = 1, NEQ
+        pdj = 0D0
+        call chem_ode_jac(NEQ, tdummy, chemsol_stor%y, j, dummy, dummy, pdj)
+        do k = chemsol_stor%IWORK(30 + j), chemsol_stor%IWORK(31 + j) - 1
+          write(fC, '(ES25.17E3)') pdj(chemsol_stor%IWORK(31 + NEQ + k))
+        end do
+      end do
+    end if
+
+    if (solve .ne. 0) then
+      call system_clock(c0, crate)
+      call chem_evol_solve
+      call system_clock(c1)
+      write(fC, '(A, I8)') '# yend ', NEQ
+      do i = 1, NEQ
+        write(fC, '(ES25.17E3)') chemsol_stor%y(i)
+      end do
+      write(fC, '(A, I8)') '# scalars ', 4
+      write(fC, '(ES25.17E3)') chemsol_stor%touts(chemsol_params%n_record_real)
+      write(fC, '(ES25.17E3)') dble(chemsol_params%quality)
+      write(fC, '(ES25.17E3)') dble(chemsol_params%NERR)
+      write(fC, '(ES25.17E3)') dble(c1 - c0) / dble(crate)
+      ! IWORK(11,12,13,21): NST NFE NJE NLU of the LAST solver segment (zeroed by every ISTATE=1)
+      write(fC, '(A, I8)') '# stats ', 9
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(11))
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(12))
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(13))
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(21))
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(19))
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(25))
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(26))
+      write(fC, '(ES25.17E3)') dble(chemsol_params%n_record)
+      write(fC, '(ES25.17E3)') dble(chemsol_params%n_record_real)
+      write(fC, '(A, I8)') '# touts ', chemsol_params%n_record
+      do i = 1, chemsol_params%n_record
+        write(fC, '(ES25.17E3)') chemsol_stor%touts(i)
+      end do
+      if (dump_record_every .gt. 0) then
+        do k = 1, chemsol_params%n_record, dump_record_every
+          write(fC, '(A, I8, I8)') '# record ', NEQ, k
+          do i = 1, NEQ
+            write(fC, '(ES25.17E3)') chemsol_stor%record(i, k)
+          end do
+        end do
+      end if
+      ! RHS at the end state: second ydot pin, at a chemically evolved composition.
+      call chem_ode_f(NEQ, tdummy, chemsol_stor%y, ydot)
+      write(fC, '(A, I8)') '# ydotend ', NEQ
+      do i = 1, NEQ
+        write(fC, '(ES25.17E3)') ydot(i)
+      end do
+    end if
+    close(fC)
+  end do
+  close(fU)
+end program ref_driver
