@@ -1,0 +1,143 @@
+/* racgpu.h -- C ABI of the MI355X-native batched chemistry engine (drop-in for rac-2d's per-cell solve).
+ *
+ * The reference has no FFI: its seam is the argument-less Fortran call `call chem_evol_solve`
+ * (reference src/disk.f90:1686) operating on module globals of `module chemistry`
+ * (src/chemistry.f90:158-170).  Each entry point below replaces one piece of that seam and cites it.
+ * Plain pointers and sizes only; all arrays are caller-owned, f64 / i32 / i64, cell-major with the
+ * species index contiguous (the reference's per-cell abundance layout, src/data_dump.f90:88-162).
+ * Species indices in this API are 1-based like the reference's (chem_species%names(1:nSpecies)).
+ *
+ * Return convention: 0 = ok, negative = error (text via racgpu_last_error()).  Per-cell outcomes
+ * (the reference's chemsol_params%quality bitmask, NERR, n_record_real, t_final) come back in arrays.
+ * Thread model: one host thread per device; a handle may be used by one thread at a time.
+ * The Fortran binding is rac-2d_amd/fortran/racgpu_mod.f90 (ISO_C_BINDING); see INTEGRATION.md.
+ */
+#ifndef RACGPU_H
+#define RACGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the per-cell input record: the fields of type_cell_rz_phy_basic that the fixed-T path reads
+ * (reference src/data_struct.f90:316-442; set by src/disk.f90:1653 `chem_params = leaves%list(id)%p%par`) */
+#define RACGPU_NPAR 28
+enum {
+  RACGPU_P_TGAS = 0,        /* Tgas                       [K]      */
+  RACGPU_P_TDUST,           /* Tdust                      [K]      */
+  RACGPU_P_NGAS,            /* n_gas                      [cm^-3]  */
+  RACGPU_P_GRAIN_RADIUS,    /* GrainRadius_CGS            [cm]     */
+  RACGPU_P_SIGDUST,         /* sigdust_ave                [cm^2]   */
+  RACGPU_P_NDUST,           /* ndust_tot                  [cm^-3]  */
+  RACGPU_P_D2H,             /* ratioDust2HnucNum                   */
+  RACGPU_P_SITES,           /* SitesPerGrain                       */
+  RACGPU_P_ALBEDO,          /* omega_albedo                        */
+  RACGPU_P_ZETA_CR,         /* zeta_cosmicray_H2          [s^-1]   */
+  RACGPU_P_ZETA_X,          /* zeta_Xray_H2               [s^-1]   */
+  RACGPU_P_NCOL_ISM,        /* Ncol_toISM                 [cm^-2]  */
+  RACGPU_P_AV_ISM,          /* Av_toISM                            */
+  RACGPU_P_AV_STAR,         /* Av_toStar                           */
+  RACGPU_P_G0_ISM,          /* G0_UV_toISM                         */
+  RACGPU_P_G0_STAR,         /* G0_UV_toStar                        */
+  RACGPU_P_G0_H2PHD,        /* G0_UV_H2phd                         */
+  RACGPU_P_G0_PHOTODES,     /* G0_UV_toStar_photoDesorb            */
+  RACGPU_P_LYA,             /* phflux_Lya                          */
+  RACGPU_P_FSS_ISM_H2, RACGPU_P_FSS_ISM_CO, RACGPU_P_FSS_ISM_H2O, RACGPU_P_FSS_ISM_OH,     /* f_selfshielding_toISM_*  */
+  RACGPU_P_FSS_STAR_H2, RACGPU_P_FSS_STAR_CO, RACGPU_P_FSS_STAR_H2O, RACGPU_P_FSS_STAR_OH, /* f_selfshielding_toStar_* */
+  RACGPU_P_TMAX             /* per-cell t_max [yr]; <= 0: use params.t_max (src/disk.f90:2078-2085 is the caller's rule) */
+};
+
+/* ---- the chemsol_params namelist scalars the path reads (reference src/chemistry.f90:107-135, 183-184) */
+typedef struct racgpu_params {
+  double RTOL, ATOL;            /* chemsol_params%RTOL, %ATOL                              */
+  double t_max;                 /* %t_max   [yr]                                           */
+  double dt_first_step;         /* %dt_first_step [yr]                                     */
+  double ratio_tstep;           /* %ratio_tstep                                            */
+  double max_runtime_allowed;   /* accepted for namelist compatibility; NOT used: the CPU-time guards of
+                                   src/chemistry.f90:480-491 are replaced by max_steps_per_cell */
+  double Diff2DesorRatio;       /* %Diff2DesorRatio (default 0.5)                          */
+  double special_gH_E_diff;     /* %special_gH_E_diff (default 225)                        */
+  int32_t mxstep_per_interval;  /* %mxstep_per_interval -> DLSODES MXSTEP (IWORK(6))       */
+  int32_t steps_reset_solver;   /* %steps_reset_solver: ISTATE=1 every this many records   */
+  int32_t H2_form_use_moeq;     /* must be 0 (the .true. branch is not implemented: error) */
+  int32_t evol_dust_size;       /* must be 0 (error otherwise)                             */
+  int32_t use_special_gH_mobi;  /* %use_special_gH_mobi                                    */
+  int32_t tol_policy_j;         /* j of chem_set_solver_flags_alt(j) (src/chemistry.f90:205); 1 = as configured */
+  int64_t max_steps_per_cell;   /* deterministic work budget (accepted steps); 0 = unlimited.  A cell that
+                                   exhausts it stops like the reference's "Premature finish" */
+} racgpu_params;
+
+/* per-cell counters returned by racgpu_solve_batch (int64 x RACGPU_NSTAT per cell) */
+#define RACGPU_NSTAT 8
+enum { RACGPU_S_NST = 0, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_NERR, RACGPU_S_NREC_REAL,
+       RACGPU_S_QSUM /* sum of the order used over accepted steps */, RACGPU_S_NCFAIL_ETFAIL };
+
+/* where the caller's cell/abundance/output buffers live */
+#define RACGPU_MEM_HOST 0
+#define RACGPU_MEM_DEVICE 1
+
+typedef struct racgpu_network racgpu_network; /* opaque: network + species tables, sparsity, symbolic LU, device copies */
+
+const char *racgpu_last_error(void);
+int racgpu_device_count(void);                      /* number of visible HIP devices (0 if none) */
+
+/* chem_read_reactions + chem_load_reactions + chem_parse_reactions + chem_get_dupli_reactions +
+ * chem_get_idx_for_special_species + chem_make_sparse_structure (+ ordering and symbolic LU, which the
+ * reference redoes per cell inside DLSODES; src/chemistry.f90:1427,1364,1221,1188,1089,1858; src/disk.f90:1566-1581).
+ * Host only: usable without a GPU.  Device tables are uploaded lazily by the first compute call. */
+racgpu_network *racgpu_network_load(const char *path);
+void racgpu_network_destroy(racgpu_network *);
+/* nnzJ: species-block Jacobian pattern actually used (dead reactions and the T row/column dropped);
+ * nzl/nzu: strict lower/upper fill of its LU.  Any pointer may be NULL. */
+int racgpu_network_dims(const racgpu_network *, int32_t *nSpecies, int32_t *nReactions, int32_t *nnzJ, int32_t *nzl, int32_t *nzu);
+int racgpu_species_name(const racgpu_network *, int32_t i, char *buf, int32_t buflen); /* chem_species%names(i) */
+int racgpu_species_index(const racgpu_network *, const char *name);                   /* 0 if absent */
+/* reaction table as parsed: reac[nR*3], prod[nR*4] (1-based, 0 = empty), n_reac, n_prod, itype, n_dupli[nR]; any may be NULL */
+int racgpu_reactions(const racgpu_network *, int32_t *reac, int32_t *prod, int32_t *n_reac, int32_t *n_prod, int32_t *itype, int32_t *n_dupli);
+/* species attributes: mass_num, vib_freq, Edesorb [nS] (NaN where the reference leaves NaN), counterpart (-1 none), charge */
+int racgpu_species_attrs(const racgpu_network *, double *mass_num, double *vib_freq, double *Edesorb, int32_t *counterpart, int32_t *charge);
+/* CSC pattern of the species-block Jacobian: colptr[nS+1], rowidx[nnzJ], 1-based */
+int racgpu_jac_pattern(const racgpu_network *, int32_t *colptr, int32_t *rowidx);
+
+/* chem_load_initial_abundances (src/chemistry.f90:1978-2024): y0[nS], neutralised and renormalised to sum(H)=1 */
+int racgpu_load_initial_abundances(const racgpu_network *, const char *path, double *y0);
+void racgpu_params_default(racgpu_params *);          /* type defaults + inp/template_configure.dat values */
+int racgpu_n_record(const racgpu_params *, double t0, double t_max); /* src/chemistry.f90:1894-1899 */
+/* chem_set_solver_flags_alt(j) (src/chemistry.f90:205-268): rtol, atol[nS+1] for one cell's ratioDust2HnucNum */
+int racgpu_set_tolerances(const racgpu_network *, const racgpu_params *, int32_t j, double d2h, double *rtol, double *atol);
+/* set_initial_condition_4solver (src/disk.f90:2055-2066): y[c,:] = y0, Grain0 slot <- ratioDust2HnucNum of the cell */
+int racgpu_init_abundances(const racgpu_network *, const double *y0, const double *cells, int64_t ncell, double *y);
+
+/* ---- device selection (one process per GPU) ---- */
+int racgpu_set_device(int dev);
+int racgpu_set_stream(racgpu_network *, void *hip_stream); /* NULL = the null stream */
+
+/* ---- test hooks mirroring chem_cal_rates / chem_ode_f / chem_ode_jac (host buffers) ---- */
+int racgpu_rates(racgpu_network *, const racgpu_params *, const double *cells, int64_t ncell, double *rates /* [ncell*nR], yr^-1 */);
+int racgpu_rhs(racgpu_network *, const racgpu_params *, const double *cells, int64_t ncell, const double *y /* [ncell*nS] */, double *ydot /* [ncell*nS] */);
+int racgpu_jac_csc(racgpu_network *, const racgpu_params *, const double *cells, int64_t ncell, const double *y, double *vals /* [ncell*nnzJ] */);
+/* solves P x = b with P = I - gamma*J(y) through the engine's own sparse LU: b in, x out [ncell*nS] */
+int racgpu_newton_solve(racgpu_network *, const racgpu_params *, const double *cells, int64_t ncell, const double *y, double gamma, double *bx);
+
+/* ---- the hot path: chem_cal_rates + chem_set_solver_flags_alt + chem_evol_solve for a batch of cells
+ * (src/disk.f90:1671-1686; src/chemistry.f90:391-588).  One cell per wavefront, all cells independent.
+ *   cells    [ncell*RACGPU_NPAR]   in
+ *   y        [ncell*nS]            in: abundances at t0 = 0; out: abundances at t_final (record(:, n_record_real))
+ *   t_final  [ncell]               out  (NULL ok)
+ *   quality  [ncell] int32         out  chemsol_params%quality bitmask {1,2,256,512} (NULL ok)
+ *   stats    [ncell*RACGPU_NSTAT]  out  int64 (NULL ok)
+ *   record   [ncell*n_record*(nS+1)] out, optional (NULL): chemsol_stor%record incl. the T slot; touts [ncell*n_record]
+ *            n_record = racgpu_n_record(params, 0, params->t_max); only allowed when no cell overrides t_max upward
+ *   mem      RACGPU_MEM_HOST: buffers are host memory (copied in/out); RACGPU_MEM_DEVICE: device pointers
+ */
+int racgpu_solve_batch(racgpu_network *, const racgpu_params *, int64_t ncell, const double *cells, double *y,
+                       double *t_final, int32_t *quality, int64_t *stats, double *record, double *touts, int mem);
+/* bytes of device workspace racgpu_solve_batch keeps per cell (grows the handle's workspace on demand) */
+int64_t racgpu_workspace_bytes_per_cell(const racgpu_network *);
+/* HIP-event time of the last racgpu_solve_batch kernel on its stream, milliseconds (-1 if none) */
+double racgpu_last_kernel_ms(const racgpu_network *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

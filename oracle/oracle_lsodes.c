@@ -15,6 +15,7 @@
  */
 #include "oracle_lsodes.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -375,6 +376,7 @@ void orc_lsodes_call(orc_lsodes *s, double *y, double *t, double tout, int *ista
     }
     if (s->tn + s->h == s->tn) s->nhnil++;
     int kflag = stode(s, y);
+    if (getenv("ORC_TRACE")) fprintf(stderr, "[oracle trace] tn=%.6e h=%.6e hu=%.6e nq=%d kflag=%d nst=%d nfe=%d nje/nlu=%d\n", s->tn, s->h, s->hu, s->nq, kflag, s->nst, s->nfe, s->nje * 10000 + s->nlu);
     if (kflag != 0) {
       if (kflag == -3) { *istate = -7; finish(s, y, t); return; }
       *istate = (kflag == -1) ? -4 : -5;

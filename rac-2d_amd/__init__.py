@@ -1,0 +1,247 @@
+"""rac-2d_amd -- host-side Python mirror of the reference's chemistry interface over the racgpu C ABI.
+
+Everything numerical happens in ``libracgpu.so`` (hand-written gfx950 kernels, see csrc/).  This module
+is plumbing: ctypes signatures for every symbol of ``include/racgpu.h`` plus thin wrappers whose names
+follow the reference's own vocabulary (``chem_cal_rates`` -> :meth:`Network.cal_rates`,
+``chem_evol_solve`` over the cell sweep -> :meth:`Network.evol_solve_batch`, ``chemsol_params`` ->
+:class:`ChemsolParams`).  There is no CPU fallback: without the built library, or without a GPU for the
+compute calls, the calls raise.
+
+The package directory name contains a hyphen (``rac-2d_amd``), so import it with
+``importlib.import_module("rac-2d_amd")``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import cells  # noqa: F401  (synthetic cell records)
+from .cells import NPAR
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libracgpu.so")
+NSTAT = 8
+MEM_HOST, MEM_DEVICE = 0, 1
+
+# every extern "C" symbol include/racgpu.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "racgpu_last_error", "racgpu_device_count", "racgpu_network_load", "racgpu_network_destroy",
+    "racgpu_network_dims", "racgpu_species_name", "racgpu_species_index", "racgpu_reactions",
+    "racgpu_species_attrs", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
+    "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
+    "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
+    "racgpu_solve_batch", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
+]
+
+
+class ChemsolParams(C.Structure):
+    """``racgpu_params``: the scalars of the reference's ``chemsol_params`` namelist variable
+    (reference src/chemistry.f90:107-135) that the path reads."""
+    _fields_ = [
+        ("RTOL", C.c_double), ("ATOL", C.c_double), ("t_max", C.c_double), ("dt_first_step", C.c_double),
+        ("ratio_tstep", C.c_double), ("max_runtime_allowed", C.c_double), ("Diff2DesorRatio", C.c_double),
+        ("special_gH_E_diff", C.c_double),
+        ("mxstep_per_interval", C.c_int32), ("steps_reset_solver", C.c_int32), ("H2_form_use_moeq", C.c_int32),
+        ("evol_dust_size", C.c_int32), ("use_special_gH_mobi", C.c_int32), ("tol_policy_j", C.c_int32),
+        ("max_steps_per_cell", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libracgpu.so (built in-tree by ``__graft_entry__.build()`` / ``make -C rac-2d_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the racgpu path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip, lp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    pp = C.POINTER(ChemsolParams)
+    L.racgpu_last_error.restype = C.c_char_p
+    L.racgpu_network_load.restype = vp
+    L.racgpu_network_load.argtypes = [C.c_char_p]
+    L.racgpu_network_destroy.argtypes = [vp]
+    L.racgpu_network_dims.argtypes = [vp, ip, ip, ip, ip, ip]
+    L.racgpu_species_name.argtypes = [vp, C.c_int32, C.c_char_p, C.c_int32]
+    L.racgpu_species_index.argtypes = [vp, C.c_char_p]
+    L.racgpu_reactions.argtypes = [vp, ip, ip, ip, ip, ip, ip]
+    L.racgpu_species_attrs.argtypes = [vp, dp, dp, dp, ip, ip]
+    L.racgpu_jac_pattern.argtypes = [vp, ip, ip]
+    L.racgpu_load_initial_abundances.argtypes = [vp, C.c_char_p, dp]
+    L.racgpu_params_default.argtypes = [pp]
+    L.racgpu_n_record.argtypes = [pp, C.c_double, C.c_double]
+    L.racgpu_set_tolerances.argtypes = [vp, pp, C.c_int32, C.c_double, dp, dp]
+    L.racgpu_init_abundances.argtypes = [vp, dp, dp, C.c_int64, dp]
+    L.racgpu_set_device.argtypes = [C.c_int]
+    L.racgpu_set_stream.argtypes = [vp, vp]
+    L.racgpu_rates.argtypes = [vp, pp, dp, C.c_int64, dp]
+    L.racgpu_rhs.argtypes = [vp, pp, dp, C.c_int64, dp, dp]
+    L.racgpu_jac_csc.argtypes = [vp, pp, dp, C.c_int64, dp, dp]
+    L.racgpu_newton_solve.argtypes = [vp, pp, dp, C.c_int64, dp, C.c_double, dp]
+    L.racgpu_solve_batch.argtypes = [vp, pp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.racgpu_workspace_bytes_per_cell.restype = C.c_int64
+    L.racgpu_workspace_bytes_per_cell.argtypes = [vp]
+    L.racgpu_last_kernel_ms.restype = C.c_double
+    L.racgpu_last_kernel_ms.argtypes = [vp]
+    _lib = L
+    return L
+
+
+class RacgpuError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise RacgpuError(lib().racgpu_last_error().decode())
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def default_params():
+    p = ChemsolParams()
+    lib().racgpu_params_default(C.byref(p))
+    return p
+
+
+def device_count():
+    return lib().racgpu_device_count()
+
+
+def set_device(dev):
+    _check(lib().racgpu_set_device(dev))
+
+
+class Network:
+    """A parsed reaction network + everything cell-independent (``chem_net``, ``chem_species``,
+    sparsity, symbolic LU).  Mirrors the reference's one-time setup sequence src/disk.f90:1566-1581."""
+
+    def __init__(self, path):
+        self._h = lib().racgpu_network_load(os.fsencode(path))
+        if not self._h:
+            raise RacgpuError(lib().racgpu_last_error().decode())
+        d = [C.c_int32() for _ in range(5)]
+        _check(lib().racgpu_network_dims(self._h, *[C.byref(x) for x in d]))
+        self.nSpecies, self.nReactions, self.nnzJ, self.nzl, self.nzu = [x.value for x in d]
+        buf = C.create_string_buffer(32)
+        self.names = []
+        for i in range(1, self.nSpecies + 1):
+            _check(lib().racgpu_species_name(self._h, i, buf, 32))
+            self.names.append(buf.value.decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().racgpu_network_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-only queries -------------------------------------------------------------------------
+    def species_index(self, name):
+        return lib().racgpu_species_index(self._h, name.encode())
+
+    def reactions(self):
+        nR = self.nReactions
+        reac = np.zeros((nR, 3), np.int32); prod = np.zeros((nR, 4), np.int32)
+        nre = np.zeros(nR, np.int32); npr = np.zeros(nR, np.int32); it = np.zeros(nR, np.int32); nd = np.zeros(nR, np.int32)
+        _check(lib().racgpu_reactions(self._h, _ip(reac), _ip(prod), _ip(nre), _ip(npr), _ip(it), _ip(nd)))
+        return dict(reac=reac, prod=prod, n_reac=nre, n_prod=npr, itype=it, n_dupli=nd)
+
+    def species_attrs(self):
+        nS = self.nSpecies
+        m = np.zeros(nS); v = np.zeros(nS); e = np.zeros(nS); cp = np.zeros(nS, np.int32); ch = np.zeros(nS, np.int32)
+        _check(lib().racgpu_species_attrs(self._h, _dp(m), _dp(v), _dp(e), _ip(cp), _ip(ch)))
+        return dict(mass_num=m, vib_freq=v, Edesorb=e, counterpart=cp, charge=ch)
+
+    def jac_pattern(self):
+        colptr = np.zeros(self.nSpecies + 1, np.int32); rowidx = np.zeros(self.nnzJ, np.int32)
+        _check(lib().racgpu_jac_pattern(self._h, _ip(colptr), _ip(rowidx)))
+        return colptr, rowidx
+
+    def load_initial_abundances(self, path):
+        y0 = np.zeros(self.nSpecies)
+        _check(lib().racgpu_load_initial_abundances(self._h, os.fsencode(path), _dp(y0)))
+        return y0
+
+    def set_solver_flags_alt(self, params, j, d2h):
+        rtol = np.zeros(self.nSpecies + 1); atol = np.zeros(self.nSpecies + 1)
+        _check(lib().racgpu_set_tolerances(self._h, C.byref(params), j, d2h, _dp(rtol), _dp(atol)))
+        return rtol, atol
+
+    def init_abundances(self, y0, cell_records):
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        y = np.zeros((cr.shape[0], self.nSpecies))
+        _check(lib().racgpu_init_abundances(self._h, _dp(np.ascontiguousarray(y0, np.float64)), _dp(cr), cr.shape[0], _dp(y)))
+        return y
+
+    def workspace_bytes_per_cell(self):
+        return lib().racgpu_workspace_bytes_per_cell(self._h)
+
+    # ---- GPU compute --------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        _check(lib().racgpu_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def cal_rates(self, params, cell_records):
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        out = np.zeros((cr.shape[0], self.nReactions))
+        _check(lib().racgpu_rates(self._h, C.byref(params), _dp(cr), cr.shape[0], _dp(out)))
+        return out
+
+    def ode_f(self, params, cell_records, y):
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        y = np.ascontiguousarray(y, np.float64).reshape(cr.shape[0], self.nSpecies)
+        out = np.zeros_like(y)
+        _check(lib().racgpu_rhs(self._h, C.byref(params), _dp(cr), cr.shape[0], _dp(y), _dp(out)))
+        return out
+
+    def ode_jac(self, params, cell_records, y):
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        y = np.ascontiguousarray(y, np.float64).reshape(cr.shape[0], self.nSpecies)
+        out = np.zeros((cr.shape[0], self.nnzJ))
+        _check(lib().racgpu_jac_csc(self._h, C.byref(params), _dp(cr), cr.shape[0], _dp(y), _dp(out)))
+        return out
+
+    def newton_solve(self, params, cell_records, y, gamma, b):
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        y = np.ascontiguousarray(y, np.float64).reshape(cr.shape[0], self.nSpecies)
+        x = np.array(b, np.float64).reshape(cr.shape[0], self.nSpecies).copy()
+        _check(lib().racgpu_newton_solve(self._h, C.byref(params), _dp(cr), cr.shape[0], _dp(y), gamma, _dp(x)))
+        return x
+
+    def evol_solve_batch(self, params, cell_records, y, record=False):
+        """chem_cal_rates + chem_set_solver_flags_alt + chem_evol_solve for every cell (host arrays)."""
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        n = cr.shape[0]
+        y = np.array(y, np.float64).reshape(n, self.nSpecies).copy()
+        tf = np.zeros(n); q = np.zeros(n, np.int32); st = np.zeros((n, NSTAT), np.int64)
+        rec = tos = None
+        if record:
+            nrec = lib().racgpu_n_record(C.byref(params), 0.0, params.t_max)
+            rec = np.zeros((n, nrec, self.nSpecies + 1)); tos = np.zeros((n, nrec))
+        _check(lib().racgpu_solve_batch(self._h, C.byref(params), n, cr.ctypes.data, y.ctypes.data, tf.ctypes.data,
+                                        q.ctypes.data, st.ctypes.data, rec.ctypes.data if record else None,
+                                        tos.ctypes.data if record else None, MEM_HOST))
+        return dict(y=y, t_final=tf, quality=q, stats=st, record=rec, touts=tos,
+                    kernel_ms=lib().racgpu_last_kernel_ms(self._h))
+
+    def evol_solve_batch_device(self, params, ncell, cells_ptr, y_ptr, t_final_ptr=None, quality_ptr=None, stats_ptr=None):
+        """Same, on device pointers (e.g. torch tensors' data_ptr()); asynchronous on the handle's stream."""
+        _check(lib().racgpu_solve_batch(self._h, C.byref(params), ncell, cells_ptr, y_ptr, t_final_ptr, quality_ptr,
+                                        stats_ptr, None, None, MEM_DEVICE))
+
+    def last_kernel_ms(self):
+        return lib().racgpu_last_kernel_ms(self._h)

@@ -1,0 +1,66 @@
+// device_tables.hpp -- plain-old-data views of the network tables as the gfx950 kernels see them.
+#pragma once
+#include <cstdint>
+
+namespace racgpu {
+
+// flux kinds (values of racgpu::Kind in network.hpp)
+constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K_SQ_ = 5;
+
+struct DevNet {
+  int nS, nR, npad;          // npad = nS rounded up to 64
+  int nnzJ, nzl, nzu;
+  // ---- rate coefficients (one row per reaction, original file order) ----
+  const int16_t *r_itype;
+  const uint16_t *r_re0, *r_re1;   // 0-based reactant species (0xFFFF none)
+  const uint8_t *r_nreac;
+  const uint8_t *r_fss;            // 0 none, 1 H2, 2 CO, 3 H2O, 4 OH
+  const uint8_t *r_flags;          // bit0: first reactant is H2; bit1: first reactant is gH; bit2: type-21 pair has opposite charges
+  const uint16_t *r_id3;           // type 21: the non-dust reactant
+  const double *r_A, *r_B, *r_C, *r_T0, *r_T1;
+  const double *s_mass, *s_vib, *s_Edes;
+  const int *dupli_ptr, *dupli_list; // 0-based reaction numbers
+  // ---- RHS: one packed row per reaction ----
+  // w0: kind | n_reac<<8 | a<<16 | b<<32 ; w1: targets 0..3 ; w2: targets 4..6 (u16 each, 0xFFFF = none);
+  // target slots 0..n_reac-1 subtract, the rest add
+  const uint64_t *rhs_w0, *rhs_w1, *rhs_w2;
+  // ---- Jacobian gather ----
+  const int *jac_order;      // entries sorted by decreasing term count, padded to a multiple of 64 with -1
+  int jac_slots;
+  const int *term_ptr;       // [nnzJ+1]
+  const uint64_t *terms;     // rxn | sa<<16 | kind<<32 | flags<<40 | sb<<48
+  const uint8_t *jac_isdiag; // [nnzJ]
+  // ---- sparse LU of the permuted species block ----
+  const uint16_t *perm;      // perm[new] = old
+  const int *Lcolptr, *Ucolptr, *Pcolptr;
+  const uint16_t *Lrow, *Urow, *Prow;
+  const int *Psrc;
+  // type-11 special indices (0-based, -1 none)
+  int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;
+  const uint8_t *s_tolclass; // 0 generic, 1 one of the ten special species, 2 Grain0/+/-, 3 surface species (applied in that order)
+};
+
+struct DevParams {
+  double RTOL, ATOL, t_max, dt_first_step, ratio_tstep, Diff2DesorRatio, special_gH_E_diff;
+  int mxstep, steps_reset, use_special_gH_mobi, tol_j;
+  long long max_steps_per_cell;
+  int n_record; // for params.t_max (record layout)
+  int debug_max_calls; // developer aid (env RACGPU_DEBUG_TRACE): stop a cell after this many step calls; 0 = off
+  double elco[6][7];  // BDF coefficients el(i), i = 1..nq+1, per order nq = 1..5 (DCFODE, reference src/opkda1.f:146-171)
+  double tesco[6][4]; // error-test constants tesco(1..3, nq)
+};
+
+struct DevWork { // per-cell workspace, all f64, cell-major
+  double *rates;   // [ncell][nR]
+  double *yh;      // [ncell][6][npad]
+  double *P;       // [ncell][nnzJ]
+  double *L;       // [ncell][nzl]
+  double *U;       // [ncell][nzu]
+  double *Dinv;    // [ncell][npad]
+  double *rtol, *atol; // [ncell][npad]
+  int *counter;    // work queue head
+  double *trace;   // developer aid: [debug_max_calls][8] step log of cell 0, or null
+  int *marker;     // developer aid: host-mapped progress word (null when off)
+};
+
+} // namespace racgpu

@@ -1,0 +1,497 @@
+// engine_integrate.hpp -- per-wave variable-order BDF integration of one cell (device code).
+//
+// What is mirrored, and where it lives in the reference:
+//   output-time loop, restart/error policy, quality flags   chem_evol_solve            src/chemistry.f90:391-588
+//   tolerance loosening after ISTATE -4/-5                  ode_solver_error_handling  src/chemistry.f90:297-377
+//   driver blocks A-H for ITASK=4 (TCRIT=HMAX=t_max)        DLSODES                    src/opkdmain.f:3069-3588
+//   one step in Nordsieck form, order/step selection        DSTODE                     src/opkda1.f:746-1124
+//   P = I - h*el0*J: evaluate or rescale, then factor       DPRJS                      src/opkda1.f:1735-1838
+//   interpolation at tout                                   DINTDY (K = 0)             src/opkda1.f:236-263
+// The T slot (NEQ = nS+1) is inert at fixed temperature: its ydot, Jacobian row and column are zero, so it is
+// carried as two scalars (value and weight) that only enter the "too much accuracy" norm and the divisor of
+// every RMS norm, exactly as in the reference.
+#pragma once
+#include "engine_device.hpp"
+
+namespace racgpu {
+
+struct CellCtx {
+  double *y, *savf, *acor, *ewt, *wx;                          // LDS, nS doubles each
+  double *yh, *Pv, *Lv, *Uv, *Dinv, *rates, *rtol, *atol;      // this cell's HBM slices
+  double nsite;   // ratioDust2HnucNum * SitesPerGrain
+  double Tgas, rT, aT;
+  int lane, n, npad;
+  double inv_neq; // 1 / (nS + 1)
+  int *marker;    // developer aid: host-visible progress word, or null
+};
+
+RG_DEV void dev_mark(const CellCtx &c, int id) {
+  if (c.marker && c.lane == 0) __hip_atomic_store(c.marker, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct Lsodes { // the scalars ODEPACK keeps in COMMON /DLS001/ and /DLSS01/ plus the driver's SAVEd locals
+  double conit, crate, hold, rmax, el0, h, hmxi, hu, rc, tn;
+  double con0, conmin, tcrit, h0;
+  int ialth, ipup, lmax, nslp, icf, ierpj, jcur, jstart, kflag, l, nq, nst, nfe, nje, nqu;
+  int iplost, nslj, nlu, init, nslast, imxer, mxstep;
+  long long qsum; int nfail;
+  int ncalls; double *trace; int trace_cap; // developer aid
+};
+
+constexpr double kUround = 2.220446049250313e-16; // DUMACH()
+constexpr double kCcmax = 0.3, kCcmxj = 0.2, kPsmall = 1000.0 * kUround, kRbig = 0.01 / kPsmall;
+constexpr int kMaxord = 5, kMaxcor = 3, kMsbp = 20, kMxncf = 10, kMsbj = 50;
+
+template <typename V>
+RG_DEV double dev_vnorm(const CellCtx &c, V v) { // DVNORM over NEQ = nS+1 entries, the T entry being zero
+  double s = 0.0;
+  for (int i = c.lane; i < c.n; i += 64) { const double q = v(i) * c.ewt[i]; s += q * q; }
+  return sqrt(wave_sum(s) * c.inv_neq);
+}
+
+RG_DEV void dev_set_order(const DevParams &P, Lsodes &s) { // DSTODE label 150
+  s.rc = s.rc * P.elco[s.nq][1] / s.el0;
+  s.el0 = P.elco[s.nq][1];
+  s.conit = 0.5 / (s.nq + 2);
+}
+
+RG_DEV void dev_rescale(const CellCtx &c, Lsodes &s, double rh, bool apply_hmin) { // DSTODE labels 170/175
+  if (apply_hmin) rh = fmax(rh, 0.0); // RH = MAX(RH, HMIN/ABS(H)) with HMIN = 0
+  rh = fmin(rh, s.rmax);
+  rh = rh / fmax(1.0, fabs(s.h) * s.hmxi * rh);
+  double r = 1.0;
+  for (int j = 2; j <= s.l; ++j) {
+    r = r * rh;
+    double *col = c.yh + (size_t)(j - 1) * c.npad;
+    for (int i = c.lane; i < c.n; i += 64) col[i] = col[i] * r;
+  }
+  s.h = s.h * rh; s.rc = s.rc * rh; s.ialth = s.l;
+}
+
+// YH <- YH * Pascal (sign = +1, also loads y <- YH(:,1)) or its inverse (sign = -1); DSTODE :865-874, :956-962
+RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward) {
+  const int nq = s.nq;
+  for (int i = c.lane; i < c.n; i += 64) {
+    double col[kMaxord + 1];
+#pragma unroll
+    for (int j = 0; j <= kMaxord; ++j) col[j] = (j <= nq) ? c.yh[(size_t)j * c.npad + i] : 0.0;
+#pragma unroll
+    for (int jb = 1; jb <= kMaxord; ++jb) {
+      if (jb > nq) break;
+#pragma unroll
+      for (int j = 0; j < kMaxord; ++j)
+        if (j >= nq - jb && j < nq) col[j] = forward ? col[j] + col[j + 1] : col[j] - col[j + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxord; ++j)
+      if (j < nq) c.yh[(size_t)j * c.npad + i] = col[j];
+  }
+}
+
+// DPRJS for MITER = 1.  y (LDS) holds the predicted values.
+RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
+  const double hl0 = s.h * s.el0, con = -hl0;
+  bool jok = true;
+  if (s.nst == 0 || s.nst >= s.nslj + kMsbj) jok = false;
+  if (s.icf == 1 && fabs(s.rc - 1.0) < kCcmxj) jok = false;
+  if (s.icf == 2) jok = false;
+  if (jok) {
+    s.jcur = 0;
+    const double rcon = con / s.con0, rcont = fabs(con) / s.conmin;
+    if (rcont > kRbig && s.iplost == 1) jok = false;
+    else {
+      bool lost = false;
+      for (int e = c.lane; e < N.nnzJ; e += 64) {
+        double pij = c.Pv[e];
+        const bool dg = N.jac_isdiag[e];
+        if (dg) { pij = pij - 1.0; if (fabs(pij) < kPsmall) lost = true; }
+        pij = pij * rcon;
+        if (dg) pij = pij + 1.0;
+        c.Pv[e] = pij;
+      }
+      if (wave_any(lost)) { s.iplost = 1; s.conmin = fmin(fabs(s.con0), s.conmin); }
+    }
+  }
+  if (!jok) {
+    s.jcur = 1; s.nje++; s.nslj = s.nst; s.iplost = 0; s.conmin = fabs(con);
+    dev_mark(c, 3000);
+    dev_build_P(N, c.rates, c.nsite, c.y, con, true, c.Pv, c.lane);
+    dev_mark(c, 3001);
+  }
+  s.nlu++; s.con0 = con; s.ierpj = 0;
+  wave_sync();
+  if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.lane)) s.ierpj = 1;
+  s.ierpj = uniform_i(wave_any(s.ierpj != 0) ? 1 : 0);
+}
+
+// One step.  Returns kflag (0, -1, -2).  Structure follows the restatement validated on the CPU side; every
+// expression keeps the reference's operand order.
+RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s) {
+  const int n = c.n, lane = c.lane, npad = c.npad;
+  double *yh = c.yh;
+  const double told = s.tn;
+  double delp = 0.0, del = 0.0, dsm = 0.0, rh = 0.0;
+  int ncf = 0, m = 0, iredo = 0;
+  s.kflag = 0; s.ierpj = 0; s.jcur = 0; s.icf = 0;
+
+  if (s.jstart == 0) {
+    s.lmax = kMaxord + 1; s.nq = 1; s.l = 2; s.ialth = 2; s.rmax = 10000.0; s.rc = 0.0;
+    s.el0 = 1.0; s.crate = 0.7; s.hold = s.h; s.nslp = 0; s.ipup = 1;
+    dev_set_order(P, s);
+  } else if (s.jstart < 0) {
+    if (s.jstart == -1) { s.ipup = 1; s.lmax = kMaxord + 1; if (s.ialth == 1) s.ialth = 2; }
+    if (s.h != s.hold) { rh = s.h / s.hold; s.h = s.hold; iredo = 3; dev_rescale(c, s, rh, false); }
+  }
+
+  for (int guard = 0; guard < 64; ++guard) { // label 200; at most 10 + 10 + a few retries are possible
+    if (fabs(s.rc - 1.0) > kCcmax) s.ipup = 1;
+    if (s.nst >= s.nslp + kMsbp) s.ipup = 1;
+    s.tn = s.tn + s.h;
+    dev_mark(c, 2000 + guard);
+    dev_pascal(c, s, true);
+    dev_mark(c, 2100 + guard);
+
+    bool converged = false;
+    for (int pass = 0; pass < 4; ++pass) { // label 220: re-entered after a P refresh (at most twice: rescaled P, then fresh J)
+      m = 0;
+      for (int i = lane; i < n; i += 64) c.y[i] = yh[i];
+      dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); s.nfe++;
+      dev_mark(c, 2200 + pass);
+      if (s.ipup > 0) {
+        dev_prjs(N, c, s);
+        dev_mark(c, 2300 + pass);
+        s.ipup = 0; s.rc = 1.0; s.nslp = s.nst; s.crate = 0.7;
+        if (s.ierpj != 0) break;
+      }
+      for (int i = lane; i < n; i += 64) c.acor[i] = 0.0;
+      bool fail410 = false;
+      for (;;) {
+        for (int i = lane; i < n; i += 64) c.y[i] = s.h * c.savf[i] - (yh[npad + i] + c.acor[i]);
+        dev_mark(c, 2400 + m);
+        dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane);
+        dev_mark(c, 2500 + m);
+        del = dev_vnorm(c, [&](int i) { return c.y[i]; });
+        const double el1 = P.elco[s.nq][1];
+        for (int i = lane; i < n; i += 64) { const double a = c.acor[i] + c.y[i]; c.acor[i] = a; c.y[i] = yh[i] + el1 * a; }
+        if (m != 0) s.crate = fmax(0.2 * s.crate, del / delp);
+        const double dcon = del * fmin(1.0, 1.5 * s.crate) / (P.tesco[s.nq][2] * s.conit);
+        if (dcon <= 1.0) { converged = true; break; }
+        m++;
+        if (m == kMaxcor) { fail410 = true; break; }
+        if (m >= 2 && del > 2.0 * delp) { fail410 = true; break; }
+        delp = del;
+        dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); s.nfe++;
+      }
+      if (converged) break;
+      if (fail410 && s.jcur != 1) { s.icf = 1; s.ipup = 1; continue; }
+      break;
+    }
+
+    if (!converged) { // label 430
+      s.icf = 2; ncf++; s.rmax = 2.0; s.tn = told; s.nfail++;
+      dev_pascal(c, s, false);
+      if (fabs(s.h) <= 0.0 || ncf == kMxncf) { s.kflag = -2; break; }
+      rh = 0.25; s.ipup = 1; iredo = 1;
+      dev_rescale(c, s, rh, true);
+      continue;
+    }
+
+    // label 450: local error test
+    s.jcur = 0;
+    if (m == 0) dsm = del / P.tesco[s.nq][2];
+    else dsm = dev_vnorm(c, [&](int i) { return c.acor[i]; }) / P.tesco[s.nq][2];
+
+    bool consider = false;
+    double rhup = 0.0;
+    if (dsm > 1.0) { // label 500
+      s.kflag = s.kflag - 1; s.tn = told; s.nfail++;
+      dev_pascal(c, s, false);
+      s.rmax = 2.0;
+      if (fabs(s.h) <= 0.0) { s.kflag = -1; break; }
+      if (s.kflag <= -3) { // label 640
+        if (s.kflag == -10) { s.kflag = -1; break; }
+        rh = 0.1;
+        s.h = s.h * rh;
+        for (int i = lane; i < n; i += 64) c.y[i] = yh[i];
+        dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); s.nfe++;
+        for (int i = lane; i < n; i += 64) yh[npad + i] = s.h * c.savf[i];
+        s.ipup = 1; s.ialth = 5;
+        if (s.nq != 1) { s.nq = 1; s.l = 2; dev_set_order(P, s); }
+        continue;
+      }
+      iredo = 2; rhup = 0.0; consider = true;
+    } else {
+      s.kflag = 0; iredo = 0; s.nst++; s.hu = s.h; s.nqu = s.nq; s.qsum += s.nq;
+      for (int j = 1; j <= s.l; ++j) {
+        const double elj = P.elco[s.nq][j];
+        double *col = yh + (size_t)(j - 1) * npad;
+        for (int i = lane; i < n; i += 64) col[i] = col[i] + elj * c.acor[i];
+      }
+      s.ialth--;
+      if (s.ialth == 0) { // label 520
+        rhup = 0.0;
+        if (s.l != s.lmax) {
+          const double *top = yh + (size_t)(s.lmax - 1) * npad;
+          for (int i = lane; i < n; i += 64) c.savf[i] = c.acor[i] - top[i];
+          const double dup = dev_vnorm(c, [&](int i) { return c.savf[i]; }) / P.tesco[s.nq][3];
+          const double exup = 1.0 / (s.l + 1);
+          rhup = 1.0 / (1.4 * pow(dup, exup) + 0.0000014);
+        }
+        consider = true;
+      } else {
+        if (s.ialth <= 1 && s.l != s.lmax) {
+          double *top = yh + (size_t)(s.lmax - 1) * npad;
+          for (int i = lane; i < n; i += 64) top[i] = c.acor[i];
+        }
+        goto done700;
+      }
+    }
+
+    if (consider) { // labels 540-630
+      const double exsm = 1.0 / s.l;
+      const double rhsm = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
+      double rhdn = 0.0;
+      if (s.nq != 1) {
+        const double *last = yh + (size_t)(s.l - 1) * npad;
+        const double ddn = dev_vnorm(c, [&](int i) { return last[i]; }) / P.tesco[s.nq][1];
+        const double exdn = 1.0 / s.nq;
+        rhdn = 1.0 / (1.3 * pow(ddn, exdn) + 0.0000013);
+      }
+      int newq, sel;
+      if (rhsm >= rhup) sel = (rhsm < rhdn) ? 1 : 0;
+      else sel = (rhup > rhdn) ? 2 : 1;
+      if (sel == 2) { // label 590
+        newq = s.l; rh = rhup;
+        if (rh < 1.1) { s.ialth = 3; goto done700; }
+        const double r = P.elco[s.nq][s.l] / s.l;
+        double *col = yh + (size_t)newq * npad;
+        for (int i = lane; i < n; i += 64) col[i] = c.acor[i] * r;
+      } else {
+        if (sel == 0) { newq = s.nq; rh = rhsm; }
+        else { newq = s.nq - 1; rh = rhdn; if (s.kflag < 0 && rh > 1.0) rh = 1.0; }
+        if (s.kflag == 0 && rh < 1.1) { s.ialth = 3; goto done700; }
+        if (s.kflag <= -2) rh = fmin(rh, 0.2);
+      }
+      if (newq != s.nq) { s.nq = newq; s.l = s.nq + 1; dev_set_order(P, s); }
+      dev_rescale(c, s, rh, true);
+      if (iredo == 0) { s.rmax = 10.0; goto done700; }
+      continue;
+    }
+  }
+  if (s.kflag == 0) s.kflag = -2; // guard exhausted: treat as repeated convergence failure (cannot happen)
+  s.hold = s.h; s.jstart = 1;
+  return s.kflag;
+
+done700: {
+    const double r = 1.0 / P.tesco[s.nqu][2];
+    for (int i = lane; i < n; i += 64) c.acor[i] = c.acor[i] * r;
+  }
+  s.hold = s.h; s.jstart = 1;
+  return s.kflag;
+}
+
+RG_DEV void dev_intdy0(const CellCtx &c, const Lsodes &s, double t) { // y <- interpolant at t
+  const double sf = (t - s.tn) / s.h;
+  for (int i = c.lane; i < c.n; i += 64) {
+    double d = c.yh[(size_t)(s.l - 1) * c.npad + i];
+    for (int j = s.nq - 1; j >= 0; --j) d = c.yh[(size_t)j * c.npad + i] + sf * d;
+    c.y[i] = d;
+  }
+}
+
+RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some weight is <= 0
+  bool bad = false;
+  for (int i = c.lane; i < c.n; i += 64) {
+    const double e = c.rtol[i] * fabs(c.yh[i]) + c.atol[i];
+    if (e <= 0.0) bad = true;
+    c.ewt[i] = 1.0 / e;
+  }
+  const double eT = c.rT * fabs(c.Tgas) + c.aT;
+  if (eT <= 0.0) bad = true;
+  return !wave_any(bad);
+}
+
+RG_DEV void dev_finish(const CellCtx &c, const Lsodes &s, double &t) { // label 580 / 400
+  for (int i = c.lane; i < c.n; i += 64) c.y[i] = c.yh[i];
+  t = s.tn;
+}
+
+// One DLSODES call, ITASK = 4.  On entry y (LDS) is the user's Y; on exit it is Y at t.
+RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s, double &t, double tout, int &istate) {
+  const double u = kUround;
+  const int n = c.n, lane = c.lane;
+  if (istate != 1 && s.init == 0) { istate = -3; return; }
+  if (istate == 1) { s.init = 0; if (tout == t) return; }
+  if (istate == 3) {
+    // DPREP reruns on ISTATE=3 and zeroes the saved P (reference src/opkda1.f:1492-1494)
+    for (int e = lane; e < N.nnzJ; e += 64) c.Pv[e] = 0.0;
+    s.jstart = -1;
+  }
+  if (istate == 1) { // Block C
+    s.h0 = 0.0;
+    s.tn = t; s.nst = 0; s.h = 1.0;
+    for (int i = lane; i < n; i += 64) c.yh[i] = c.y[i];
+    dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); s.nfe = 1;
+    for (int i = lane; i < n; i += 64) c.yh[c.npad + i] = c.savf[i];
+    if (!dev_ewset(c)) { istate = -3; return; }
+    for (int e = lane; e < N.nnzJ; e += 64) c.Pv[e] = 0.0;
+    if ((s.tcrit - tout) * (tout - t) < 0.0) { istate = -3; return; }
+    s.jstart = 0; s.nslj = 0; s.nje = 0; s.nlu = 0; s.nslast = 0; s.hu = 0.0; s.nqu = 0;
+    {
+      const double tdist = fabs(tout - t), w0 = fmax(fabs(t), fabs(tout));
+      if (tdist < 2.0 * u * w0) { istate = -3; return; }
+      double tol = 0.0;
+      for (int i = lane; i < n; i += 64) tol = fmax(tol, c.rtol[i]);
+#pragma unroll
+      for (int mm = 32; mm >= 1; mm >>= 1) tol = fmax(tol, __shfl_xor(tol, mm, 64));
+      tol = uniform_d(fmax(tol, c.rT));
+      if (tol <= 0.0) {
+        double tl = 0.0;
+        for (int i = lane; i < n; i += 64) { const double ay = fabs(c.y[i]); if (ay != 0.0) tl = fmax(tl, c.atol[i] / ay); }
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) tl = fmax(tl, __shfl_xor(tl, mm, 64));
+        tol = uniform_d(tl);
+        if (c.Tgas != 0.0) tol = fmax(tol, c.aT / fabs(c.Tgas));
+      }
+      tol = fmax(tol, 100.0 * u); tol = fmin(tol, 0.001);
+      double sum = dev_vnorm(c, [&](int i) { return c.savf[i]; });
+      sum = 1.0 / (tol * w0 * w0) + tol * sum * sum;
+      s.h0 = 1.0 / sqrt(sum);
+      s.h0 = fmin(s.h0, tdist);
+      s.h0 = copysign(s.h0, tout - t);
+    }
+    const double rh = fabs(s.h0) * s.hmxi;
+    if (rh > 1.0) s.h0 = s.h0 / rh;
+    s.h = s.h0;
+    for (int i = lane; i < n; i += 64) c.yh[c.npad + i] = s.h0 * c.yh[c.npad + i];
+  } else { // Block D
+    s.nslast = s.nst;
+    if ((s.tn - s.tcrit) * s.h > 0.0) { istate = -3; return; }
+    if ((s.tcrit - tout) * s.h < 0.0) { istate = -3; return; }
+    if ((s.tn - tout) * s.h >= 0.0) { dev_intdy0(c, s, tout); t = tout; istate = 2; return; }
+    const double hmx = fabs(s.tn) + fabs(s.h);
+    if (fabs(s.tn - s.tcrit) <= 100.0 * u * hmx) { dev_finish(c, s, t); t = s.tcrit; istate = 2; return; }
+    const double tnext = s.tn + s.h * (1.0 + 4.0 * u);
+    if ((tnext - s.tcrit) * s.h > 0.0) {
+      s.h = (s.tcrit - s.tn) * (1.0 - 4.0 * u);
+      if (istate == 2) s.jstart = -2;
+    }
+  }
+  bool first = (istate == 1);
+  for (;;) { // Block E
+    if (!first) {
+      if (s.nst - s.nslast >= s.mxstep) { istate = -1; dev_finish(c, s, t); return; }
+      if (!dev_ewset(c)) { istate = -6; dev_finish(c, s, t); return; }
+    }
+    first = false;
+    {
+      double q = 0.0;
+      for (int i = lane; i < n; i += 64) { const double v = c.yh[i] * c.ewt[i]; q += v * v; }
+      const double vT = c.Tgas / (c.rT * fabs(c.Tgas) + c.aT);
+      const double tolsf = u * sqrt((wave_sum(q) + vT * vT) * c.inv_neq);
+      if (tolsf > 1.0) {
+        if (s.nst == 0) { istate = -3; return; }
+        istate = -2; dev_finish(c, s, t); return;
+      }
+    }
+    dev_mark(c, 100000 + s.nst);
+    const int kflag = dev_stode(N, P, c, s);
+    dev_mark(c, 200000 + s.nst);
+    if (s.trace_cap > 0) {
+      if (s.trace && s.ncalls < s.trace_cap && lane == 0) {
+        double *tr = s.trace + (size_t)s.ncalls * 8;
+        tr[0] = s.tn; tr[1] = s.h; tr[2] = s.hu; tr[3] = s.nq; tr[4] = kflag; tr[5] = s.nst; tr[6] = s.nfe; tr[7] = s.nje * 10000.0 + s.nlu;
+      }
+      if (++s.ncalls >= s.trace_cap) { istate = -3; dev_finish(c, s, t); return; }
+    }
+    if (kflag != 0) {
+      istate = (kflag == -1) ? -4 : -5;
+      // IMXER: first index of the largest |acor*ewt| (label 560)
+      double big = -1.0; int idx = 0x7fffffff;
+      for (int i = lane; i < n; i += 64) { const double sz = fabs(c.acor[i] * c.ewt[i]); if (sz > big) { big = sz; idx = i; } }
+#pragma unroll
+      for (int mm = 32; mm >= 1; mm >>= 1) {
+        const double ob = __shfl_xor(big, mm, 64); const int oi = __shfl_xor(idx, mm, 64);
+        if (ob > big || (ob == big && oi < idx)) { big = ob; idx = oi; }
+      }
+      s.imxer = uniform_i(big > 0.0 ? idx : 0);
+      dev_finish(c, s, t); return;
+    }
+    s.init = 1;
+    if ((s.tn - tout) * s.h >= 0.0) { dev_intdy0(c, s, tout); t = tout; istate = 2; return; }
+    const double hmx = fabs(s.tn) + fabs(s.h);
+    if (fabs(s.tn - s.tcrit) <= 100.0 * u * hmx) { dev_finish(c, s, t); t = s.tcrit; istate = 2; return; }
+    const double tnext = s.tn + s.h * (1.0 + 4.0 * u);
+    if ((tnext - s.tcrit) * s.h > 0.0) { s.h = (s.tcrit - s.tn) * (1.0 - 4.0 * u); s.jstart = -2; }
+  }
+}
+
+// chem_evol_solve for one cell.  y (LDS) in: abundances at t0 = 0; out: abundances at t_final.
+struct CellResult { double t_final; int quality, nerr, nrec_real; long long nst, nfe, nje, nlu, qsum; int nfail; };
+
+RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const CellCtx &c, double t_max, int n_record,
+                                 double *__restrict__ record, double *__restrict__ touts, double *trace) {
+  Lsodes s{};
+  s.trace = trace; s.trace_cap = P.debug_max_calls;
+  s.tcrit = t_max; s.hmxi = (t_max > 0.0) ? 1.0 / t_max : 0.0; s.mxstep = P.mxstep > 0 ? P.mxstep : 500;
+  CellResult R{};
+  int istate = 1, nerr = 0, nerr_c = 0, qual = 0, nrr = 1;
+  double t = 0.0, t_step = P.dt_first_step, tout = t + t_step;
+  long long nst_acc = 0, nfe_acc = 0, nje_acc = 0, nlu_acc = 0;
+  const int lane = c.lane, n = c.n, neq = c.n + 1;
+  if (touts) { if (lane == 0) touts[0] = t; }
+  if (record) { for (int i = lane; i < n; i += 64) record[i] = c.y[i]; if (lane == 0) record[n] = c.Tgas; }
+  for (int i = 2; i <= n_record; ++i) {
+    if (tout >= t_max) tout = t_max;
+    const bool restart = (istate == 1);
+    const int nst0 = restart ? 0 : s.nst, nfe0 = restart ? 0 : s.nfe, nje0 = restart ? 0 : s.nje, nlu0 = restart ? 0 : s.nlu;
+    dev_lsodes_call(N, P, c, s, t, tout, istate);
+    nst_acc += s.nst - nst0; nfe_acc += s.nfe - nfe0; nje_acc += s.nje - nje0; nlu_acc += s.nlu - nlu0;
+    wave_sync();
+    if (touts) { if (lane == 0) touts[i - 1] = t; }
+    if (record) { double *rec = record + (size_t)(i - 1) * neq; for (int k = lane; k < n; k += 64) rec[k] = c.y[k]; if (lane == 0) rec[n] = c.Tgas; }
+    nrr = i;
+    if (P.max_steps_per_cell > 0 && nst_acc >= P.max_steps_per_cell) break; // deterministic "Premature finish"
+    if (t >= t_max) break;
+    if (istate < 0) {
+      nerr++; nerr_c++;
+      if (istate == -4 || istate == -5) { // loosen the offending component's tolerances
+        const int idx = s.imxer;
+        if (lane == 0) { c.rtol[idx] = fmin(c.rtol[idx] * 10.0, 1e-3); c.atol[idx] = fmin(c.atol[idx] * 100.0, 1e-20); }
+        wave_sync();
+      }
+      if (istate == -3) { qual += 256; break; }
+      if (nerr_c < 3) istate = 3; else { istate = 1; nerr_c = 0; }
+    }
+    {
+      bool bad = !(c.Tgas > 0.0);
+      if (N.i_gH2 >= 0 && fabs(c.y[N.i_gH2]) > 1.0) bad = true;
+      if (N.i_gH2O >= 0 && fabs(c.y[N.i_gH2O]) > 1.0) bad = true;
+      if (N.i_gH >= 0 && fabs(c.y[N.i_gH]) > 1.0) bad = true;
+      if (N.i_H >= 0 && fabs(c.y[N.i_H]) > 2.0) bad = true;
+      if (N.i_E >= 0 && fabs(c.y[N.i_E]) > 1.0) bad = true;
+      if (wave_any(bad)) { qual += 512; break; }
+    }
+    if (P.steps_reset > 0 && i % P.steps_reset == 0) istate = 1;
+    t_step = t_step * P.ratio_tstep;
+    tout = t + t_step;
+  }
+  dev_mark(c, 300 + nrr);
+  if (touts) { if (lane == 0) for (int i = nrr + 1; i <= n_record; ++i) touts[i - 1] = t; }
+  dev_mark(c, 400);
+  if (record) {
+    for (int i = nrr + 1; i <= n_record; ++i) {
+      double *rec = record + (size_t)(i - 1) * neq;
+      for (int k = lane; k < n; k += 64) rec[k] = c.y[k];
+      if (lane == 0) rec[n] = c.Tgas;
+    }
+  }
+  dev_mark(c, 401);
+  if (nerr > (int)(0.1f * (float)n_record)) qual += 1;
+  if (t <= 0.5 * t_max) qual += 2;
+  R.t_final = t; R.quality = qual; R.nerr = nerr; R.nrec_real = nrr;
+  R.nst = nst_acc; R.nfe = nfe_acc; R.nje = nje_acc; R.nlu = nlu_acc; R.qsum = s.qsum; R.nfail = s.nfail;
+  return R;
+}
+
+} // namespace racgpu

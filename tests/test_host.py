@@ -1,0 +1,111 @@
+"""Host-side (no GPU) checks of the product library: it loads, exports the whole C ABI, and its parser,
+species bookkeeping, tolerance policy and symbolic factorisation agree with the reference fixtures.
+No compute entry point is called here; without a GPU they must fail loudly, which is also checked."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN_TAGS, ROOT, load_golden
+
+
+def test_abi_exports_every_declared_symbol(racgpu):
+    lib = racgpu.lib()
+    hdr = open(os.path.join(ROOT, "include", "racgpu.h")).read()
+    declared = set(re.findall(r"\b(racgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(racgpu.ABI_SYMBOLS), declared ^ set(racgpu.ABI_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert ctypes.sizeof(racgpu.ChemsolParams) == 8 * 8 + 6 * 4 + 8
+
+
+@pytest.mark.parametrize("tag", GOLDEN_TAGS)
+def test_parser_matches_reference(racgpu, tag):
+    g = load_golden(tag)
+    net = racgpu.Network(f"{DATA}/{g['network_file']}")
+    assert net.names == list(g["species"])
+    rx = net.reactions()
+    for k in ("reac", "prod", "n_reac", "n_prod", "itype", "n_dupli"):
+        np.testing.assert_array_equal(rx[k], g[k])
+    at = net.species_attrs()
+    for k in ("mass_num", "vib_freq", "Edesorb", "counterpart", "charge"):
+        np.testing.assert_array_equal(at[k], g[k])
+    np.testing.assert_array_equal(net.load_initial_abundances(f"{DATA}/{g['initial_file']}"), g["y0"])
+    p = racgpu.default_params(); p.RTOL = float(g["rtol"])
+    for c, cell in enumerate(g["cells"]):
+        rt, at_ = net.set_solver_flags_alt(p, 1, cell[6])
+        np.testing.assert_array_equal(rt, g["rtols"][c]); np.testing.assert_array_equal(at_, g["atols"][c])
+    y = net.init_abundances(g["y0"], g["cells"])
+    i0 = net.species_index("Grain0")
+    for c, cell in enumerate(g["cells"]):
+        exp = g["y0"].copy()
+        if i0:
+            exp[i0 - 1] = cell[6]
+        np.testing.assert_array_equal(y[c], exp)
+
+
+@pytest.mark.parametrize("tag", GOLDEN_TAGS)
+def test_pattern_is_reference_pattern_minus_structural_zeros(racgpu, tag):
+    g = load_golden(tag)
+    net = racgpu.Network(f"{DATA}/{g['network_file']}")
+    nS = net.nSpecies
+    colptr, rowidx = net.jac_pattern()
+    ours = {(int(rowidx[q]), j + 1) for j in range(nS) for q in range(colptr[j] - 1, colptr[j + 1] - 1)}
+    ref = {(int(g["JA"][q]), j + 1) for j in range(nS) for q in range(g["IA"][j] - 1, g["IA"][j + 1] - 1) if g["JA"][q] <= nS}
+    assert ours - ref <= {(i, i) for i in range(1, nS + 1)}  # we only add missing diagonals (DPREP does too)
+    assert all(r == c or True for r, c in ours)
+    # everything of the reference we drop carries an exact zero in its Jacobian fixture (cell 0)
+    pos = {(int(g["JA"][q]), j + 1): q for j in range(nS) for q in range(g["IA"][j] - 1, g["IA"][j + 1] - 1)}
+    for key in ref - ours:
+        assert g["jac0"][pos[key]] == 0.0
+    # fill of our ordering vs YSMP's on the reference pattern (IWORK(25), IWORK(26)); ours has fewer rows/cols
+    assert net.nzl + net.nzu <= 1.02 * (g["stats"][0, 5] + g["stats"][0, 6])
+
+
+def test_n_record_and_defaults(racgpu):
+    p = racgpu.default_params()
+    assert (p.RTOL, p.ATOL, p.t_max, p.dt_first_step, p.ratio_tstep) == (1e-4, 1e-30, 1e6, 1e-8, 1.1)
+    assert (p.mxstep_per_interval, p.steps_reset_solver) == (6000, 50)
+    assert racgpu.lib().racgpu_n_record(ctypes.byref(p), 0.0, 1e6) == 316
+
+
+def test_errors_are_reported(racgpu):
+    with pytest.raises(racgpu.RacgpuError):
+        racgpu.Network("/nonexistent/network.dat")
+    net = racgpu.Network(f"{DATA}/rate06_dipole_reformated_again_withoutgrain.dat")
+    with pytest.raises(racgpu.RacgpuError):
+        net.load_initial_abundances("/nonexistent/abund.dat")
+
+
+def test_compute_fails_loudly_without_gpu(racgpu):
+    if racgpu.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    net = racgpu.Network(f"{DATA}/rate06_dipole_reformated_again_withoutgrain.dat")
+    cell = racgpu.cells.make_cell(50.0, 40.0, 1e8, 5.0, 1e3)
+    with pytest.raises(racgpu.RacgpuError, match="no CPU fallback|HIP"):
+        net.cal_rates(racgpu.default_params(), cell)
+
+
+def test_ragged_and_comment_rows(racgpu, tmp_path):
+    """Edge cases of the row format: comment/blank lines, D exponents, blank numeric fields, PHOTON/CRP slots."""
+    rows = [
+        "! a comment",
+        "",
+        "H2          PHOTON                  H           H                                    4D-11        0.00      2.6    10 41000  3 C PH M",
+        "H           CRP                     H+          E-                                   5.98e-18     0.00      0.0    10 41000  1 C CP M",
+        "H                                   gH                                               1.0                                    61",
+        "gH                                  H                                                1.0                  450.0             62      !HH93",
+    ]
+    f = tmp_path / "mini.dat"
+    f.write_text("\n".join(rows) + "\n")
+    net = racgpu.Network(str(f))
+    assert net.names == ["H2", "H", "H+", "E-", "gH"]
+    rx = net.reactions()
+    np.testing.assert_array_equal(rx["n_reac"], [1, 1, 1, 1])
+    np.testing.assert_array_equal(rx["n_prod"], [2, 2, 1, 1])
+    np.testing.assert_array_equal(rx["itype"], [3, 1, 61, 62])
+    at = net.species_attrs()
+    assert at["Edesorb"][4] == 450.0 and at["counterpart"][4] == 2 and at["counterpart"][1] == 5
+    assert at["charge"].tolist() == [0, 0, 1, -1, 0]
