@@ -191,6 +191,10 @@ def main():
             "cell_steps_per_pass_rank0": nst, "mean_steps_per_cell": nst / ncell,
             "nfe_per_step": nfe / max(nst, 1), "nlu_per_step": nlu / max(nst, 1), "nje_per_step": nje / max(nst, 1),
             "mean_order": qsum / max(nst, 1), "cells_with_quality_flags": int((qual != 0).sum()),
+            # share of each wave's shader-clock cycles per phase (in-kernel s_memtime brackets, summed over cells)
+            "phase_cycle_share": {k: float(stats[:, i].sum()) / max(float(stats[:, 8].sum()), 1.0)
+                                  for k, i in (("rhs", 9), ("jacobian", 10), ("lu", 11), ("tri_solve", 12))},
+            "wave_cycles_per_cell_step": float(stats[:, 8].sum()) / max(nst, 1.0),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cells_h, os.path.join(DATA, INITIAL), stats[:, 0])

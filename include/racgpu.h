@@ -68,9 +68,11 @@ typedef struct racgpu_params {
 } racgpu_params;
 
 /* per-cell counters returned by racgpu_solve_batch (int64 x RACGPU_NSTAT per cell) */
-#define RACGPU_NSTAT 8
+#define RACGPU_NSTAT 16
 enum { RACGPU_S_NST = 0, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_NERR, RACGPU_S_NREC_REAL,
-       RACGPU_S_QSUM /* sum of the order used over accepted steps */, RACGPU_S_NCFAIL_ETFAIL };
+       RACGPU_S_QSUM /* sum of the order used over accepted steps */, RACGPU_S_NCFAIL_ETFAIL,
+       /* shader-clock cycles of the cell's wave, whole solve and per phase (f(y), Jacobian, LU, triangular solves) */
+       RACGPU_S_CYC_TOTAL, RACGPU_S_CYC_RHS, RACGPU_S_CYC_JAC, RACGPU_S_CYC_LU, RACGPU_S_CYC_SOLVE };
 
 /* where the caller's cell/abundance/output buffers live */
 #define RACGPU_MEM_HOST 0

@@ -20,7 +20,7 @@ from .cells import NPAR
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libracgpu.so")
-NSTAT = 8
+NSTAT = 16
 MEM_HOST, MEM_DEVICE = 0, 1
 
 # every extern "C" symbol include/racgpu.h declares (tests check that the library exports all of them)

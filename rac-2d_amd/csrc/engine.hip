@@ -109,6 +109,8 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
     dev_mark(c, 10 + cell);
     if (cell >= ncell) break;
     const double *cp = cells + (size_t)cell * RACGPU_NPAR;
+    const long long cyc0 = dev_clock();
+    c.cyc_rhs = c.cyc_jac = c.cyc_lu = c.cyc_solve = 0;
     c.Tgas = cp[RACGPU_P_TGAS]; c.nsite = cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES];
     const double t_max = cp[RACGPU_P_TMAX] > 0.0 ? cp[RACGPU_P_TMAX] : P.t_max;
     const int n_record = (int)ceil(log((t_max - 0.0) / P.dt_first_step * (P.ratio_tstep - 1.0) + 1.0) / log(P.ratio_tstep)) + 1;
@@ -133,6 +135,8 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
         long long *s = stats + (size_t)cell * RACGPU_NSTAT;
         s[RACGPU_S_NST] = R.nst; s[RACGPU_S_NFE] = R.nfe; s[RACGPU_S_NJE] = R.nje; s[RACGPU_S_NLU] = R.nlu;
         s[RACGPU_S_NERR] = R.nerr; s[RACGPU_S_NREC_REAL] = R.nrec_real; s[RACGPU_S_QSUM] = R.qsum; s[RACGPU_S_NCFAIL_ETFAIL] = R.nfail;
+        s[RACGPU_S_CYC_TOTAL] = dev_clock() - cyc0; s[RACGPU_S_CYC_RHS] = c.cyc_rhs; s[RACGPU_S_CYC_JAC] = c.cyc_jac;
+        s[RACGPU_S_CYC_LU] = c.cyc_lu; s[RACGPU_S_CYC_SOLVE] = c.cyc_solve;
       }
     }
     dev_mark(c, 6);

@@ -23,7 +23,10 @@ struct CellCtx {
   int lane, n, npad;
   double inv_neq; // 1 / (nS + 1)
   int *marker;    // developer aid: host-visible progress word, or null
+  mutable long long cyc_rhs, cyc_jac, cyc_lu, cyc_solve; // shader-clock cycles spent per phase (s_memtime)
 };
+
+RG_DEV long long dev_clock() { return (long long)__builtin_readcyclecounter(); }
 
 RG_DEV void dev_mark(const CellCtx &c, int id) {
   if (c.marker && c.lane == 0) __hip_atomic_store(c.marker, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -115,12 +118,12 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   if (!jok) {
     s.jcur = 1; s.nje++; s.nslj = s.nst; s.iplost = 0; s.conmin = fabs(con);
     dev_mark(c, 3000);
-    dev_build_P(N, c.rates, c.nsite, c.y, con, true, c.Pv, c.lane);
+    { const long long t0 = dev_clock(); dev_build_P(N, c.rates, c.nsite, c.y, con, true, c.Pv, c.lane); c.cyc_jac += dev_clock() - t0; }
     dev_mark(c, 3001);
   }
   s.nlu++; s.con0 = con; s.ierpj = 0;
   wave_sync();
-  if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.lane)) s.ierpj = 1;
+  { const long long t0 = dev_clock(); if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.lane)) s.ierpj = 1; c.cyc_lu += dev_clock() - t0; }
   s.ierpj = uniform_i(wave_any(s.ierpj != 0) ? 1 : 0);
 }
 
@@ -155,7 +158,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     for (int pass = 0; pass < 4; ++pass) { // label 220: re-entered after a P refresh (at most twice: rescaled P, then fresh J)
       m = 0;
       for (int i = lane; i < n; i += 64) c.y[i] = yh[i];
-      dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); s.nfe++;
+      { const long long t0 = dev_clock(); dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); c.cyc_rhs += dev_clock() - t0; } s.nfe++;
       dev_mark(c, 2200 + pass);
       if (s.ipup > 0) {
         dev_prjs(N, c, s);
@@ -168,7 +171,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       for (;;) {
         for (int i = lane; i < n; i += 64) c.y[i] = s.h * c.savf[i] - (yh[npad + i] + c.acor[i]);
         dev_mark(c, 2400 + m);
-        dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane);
+        { const long long t0 = dev_clock(); dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane); c.cyc_solve += dev_clock() - t0; }
         dev_mark(c, 2500 + m);
         del = dev_vnorm(c, [&](int i) { return c.y[i]; });
         const double el1 = P.elco[s.nq][1];
@@ -180,7 +183,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (m == kMaxcor) { fail410 = true; break; }
         if (m >= 2 && del > 2.0 * delp) { fail410 = true; break; }
         delp = del;
-        dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); s.nfe++;
+        { const long long t0 = dev_clock(); dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); c.cyc_rhs += dev_clock() - t0; } s.nfe++;
       }
       if (converged) break;
       if (fail410 && s.jcur != 1) { s.icf = 1; s.ipup = 1; continue; }

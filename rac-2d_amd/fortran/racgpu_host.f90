@@ -1,0 +1,117 @@
+! racgpu_host.f90 -- Fortran host for the batched GPU chemistry solve.
+!
+!   racgpu_host <configure.dat> <cells.txt> <out_prefix>
+!
+! Plays the part of rac-2d's cell sweep (do_chemical_stuff -> calc_this_cell, reference src/disk.f90:864-938,
+! 1629-1801) for a table of frozen per-cell input records: reads the reference's own `&chemistry_configure`
+! namelist, loads the network and initial abundances through the C ABI, sets every cell's initial condition
+! (y <- y0, Grain0 <- ratioDust2HnucNum; src/disk.f90:2055-2066), solves all cells in one GPU call and writes
+!   <out_prefix>.bin : direct-access records in the layout of the reference's chemical_data_iter_NNNN.bin
+!                      (record i = cell i = abundances(nSpecies), col_den_toStar(10), col_den_toISM(10), all f64;
+!                      reference src/data_dump.f90:88-162; the 20 column densities belong to the caller: zeros)
+!   <out_prefix>.dat : one row per cell: t_final, quality, NST, then abundances in ES14.5E3 under an A14 header
+!                      (the trailing columns of the reference's iter_NNNN.dat, src/disk.f90:2749-2750, 3072)
+program racgpu_host
+  use, intrinsic :: iso_c_binding
+  use racgpu
+  implicit none
+  character(len=512) :: f_conf, f_cells, prefix, path
+  character(kind=c_char), dimension(32) :: nbuf
+  character(len=12), allocatable :: names(:)
+  type(c_ptr) :: net
+  type(racgpu_params_t) :: p
+  integer(c_int32_t) :: nS, nR, nnzJ, nzl, nzu
+  integer :: fu, ios, ncell, i, k, rc, reclen
+  real(c_double), allocatable, target :: cells(:, :), y(:, :), y0(:), t_final(:)
+  integer(c_int32_t), allocatable, target :: quality(:)
+  integer(c_int64_t), allocatable, target :: stats(:, :)
+  real(c_double) :: row(RACGPU_NPAR), zeros20(20)
+  character(len=64) :: fmt
+
+  if (command_argument_count() < 3) then
+    write(*, '(A)') 'usage: racgpu_host <configure.dat> <cells.txt> <out_prefix>'
+    stop 2
+  end if
+  call get_command_argument(1, f_conf)
+  call get_command_argument(2, f_cells)
+  call get_command_argument(3, prefix)
+
+  open(newunit=fu, file=trim(f_conf), status='old', action='read')
+  call chemistry_configure_read(fu, ios)
+  close(fu)
+  if (ios /= 0) then
+    write(*, '(A, I6)') 'cannot read &chemistry_configure, iostat = ', ios
+    stop 1
+  end if
+  call chemsol_to_c(p)
+
+  if (racgpu_device_count() < 1) then
+    write(*, '(A)') 'racgpu_host: no HIP device visible (the racgpu path has no CPU fallback)'
+    stop 1
+  end if
+
+  path = trim(chemsol_params%chem_files_dir) // trim(chemsol_params%filename_chemical_network)
+  net = racgpu_network_load(c_string(trim(path)))
+  if (.not. c_associated(net)) then
+    write(*, '(A)') 'racgpu_network_load: ' // trim(racgpu_error_string())
+    stop 1
+  end if
+  rc = racgpu_network_dims(net, nS, nR, nnzJ, nzl, nzu)
+  write(*, '(A, I6, A, I6, A, I7, A, I7)') 'Number of species ', nS, '  reactions ', nR, '  nnz(J) ', nnzJ, '  nnz(LU) ', nzl + nzu + nS
+  allocate(names(nS), y0(nS))
+  do i = 1, nS
+    rc = racgpu_species_name(net, int(i, c_int32_t), nbuf, 32_c_int32_t)
+    names(i) = ''
+    do k = 1, 12
+      if (nbuf(k) == c_null_char) exit
+      names(i)(k:k) = nbuf(k)
+    end do
+  end do
+  path = trim(chemsol_params%chem_files_dir) // trim(chemsol_params%filename_initial_abundances)
+  rc = racgpu_load_initial_abundances(net, c_string(trim(path)), y0)
+  if (rc /= 0) then
+    write(*, '(A)') 'racgpu_load_initial_abundances: ' // trim(racgpu_error_string())
+    stop 1
+  end if
+
+  ! cell table: RACGPU_NPAR numbers per row
+  ncell = 0
+  open(newunit=fu, file=trim(f_cells), status='old', action='read')
+  do
+    read(fu, *, iostat=ios) row
+    if (ios /= 0) exit
+    ncell = ncell + 1
+  end do
+  rewind(fu)
+  allocate(cells(RACGPU_NPAR, ncell), y(nS, ncell), t_final(ncell), quality(ncell), stats(RACGPU_NSTAT, ncell))
+  do i = 1, ncell
+    read(fu, *) cells(:, i)
+  end do
+  close(fu)
+
+  rc = racgpu_init_abundances(net, y0, cells, int(ncell, c_int64_t), y)
+  rc = racgpu_solve_batch(net, p, int(ncell, c_int64_t), c_loc(cells), c_loc(y), c_loc(t_final), c_loc(quality), &
+                          c_loc(stats), c_null_ptr, c_null_ptr, RACGPU_MEM_HOST)
+  if (rc /= 0) then
+    write(*, '(A)') 'racgpu_solve_batch: ' // trim(racgpu_error_string())
+    stop 1
+  end if
+  write(*, '(A, I8, A, F10.2, A, I12)') 'Solved ', ncell, ' cells; kernel ', racgpu_last_kernel_ms(net), ' ms; total steps ', sum(stats(1, :))
+
+  zeros20 = 0D0
+  inquire(iolength=reclen) y(:, 1), zeros20
+  open(newunit=fu, file=trim(prefix) // '.bin', access='direct', form='unformatted', recl=reclen, status='replace')
+  do i = 1, ncell
+    write(fu, rec=i) y(:, i), zeros20
+  end do
+  close(fu)
+  open(newunit=fu, file=trim(prefix) // '.dat', status='replace')
+  write(fmt, '("(", I4, "A14)")') nS + 3
+  write(fu, fmt) '  t_final     ', '  quality     ', '  NST         ', (adjustr(names(i) // '  '), i = 1, nS)
+  write(fmt, '("(ES14.5E3, 2I14, ", I4, "ES14.5E3)")') nS
+  do i = 1, ncell
+    write(fu, fmt) t_final(i), quality(i), int(stats(1, i)), y(:, i)
+  end do
+  close(fu)
+  call racgpu_network_destroy(net)
+end program racgpu_host

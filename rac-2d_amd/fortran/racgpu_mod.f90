@@ -1,0 +1,217 @@
+! racgpu_mod.f90 -- ISO_C_BINDING view of include/racgpu.h plus the host-side mirror of the reference's
+! chemistry interface for the per-cell solve.
+!
+! A Fortran host (rac-2d's disk.f90-style cell sweep) uses this module instead of `module chemistry` for the
+! hot path: it keeps the `&chemistry_configure` namelist (one derived-type variable `chemsol_params`, same
+! component names as the reference's type_chemical_evol_solver_params, reference src/chemistry.f90:107-135,
+! 183-184), the network / initial-abundance file formats and the cell-major, species-contiguous abundance
+! layout; the work itself happens in libracgpu.so on the GPU.
+module racgpu
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+  public :: racgpu_params_t, type_chemical_evol_solver_params, chemsol_params, chemistry_configure_read
+  public :: RACGPU_NPAR, RACGPU_NSTAT, RACGPU_MEM_HOST, RACGPU_MEM_DEVICE
+  public :: racgpu_network_load, racgpu_network_destroy, racgpu_network_dims, racgpu_species_name, &
+            racgpu_species_index, racgpu_load_initial_abundances, racgpu_params_default, racgpu_n_record, &
+            racgpu_set_tolerances, racgpu_init_abundances, racgpu_set_device, racgpu_device_count, &
+            racgpu_solve_batch, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
+  public :: racgpu_error_string, chemsol_to_c, c_string
+
+  integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 16, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
+
+  ! struct racgpu_params (include/racgpu.h)
+  type, bind(c) :: racgpu_params_t
+    real(c_double) :: RTOL, ATOL, t_max, dt_first_step, ratio_tstep, max_runtime_allowed, Diff2DesorRatio, special_gH_E_diff
+    integer(c_int32_t) :: mxstep_per_interval, steps_reset_solver, H2_form_use_moeq, evol_dust_size, &
+                          use_special_gH_mobi, tol_policy_j
+    integer(c_int64_t) :: max_steps_per_cell
+  end type racgpu_params_t
+
+  ! The namelist variable.  Component names and defaults follow the reference's declaration so that an
+  ! existing configure file is accepted verbatim; components the GPU path does not use are still parsed.
+  type :: type_chemical_evol_solver_params
+    character(len=128) :: chem_files_dir = './inp/', filename_chemical_network = '', &
+                          filename_initial_abundances = '', filename_species_enthalpy = ''
+    double precision :: RTOL = 1D-4, ATOL = 1D-30
+    double precision :: t0 = 0D0, t_max = 1D6, t_max0 = 1D6, dt_first_step = 1D-6, dt_first_step0 = 0D0, &
+                        ratio_tstep = 1.1D0, t_scale_tol = 0D0
+    logical :: H2_form_use_moeq = .false.
+    real :: max_runtime_allowed = 3600.0
+    integer :: mxstep_per_interval = 2000
+    integer :: n_record = 0, n_record_real = 0
+    integer :: NEQ = 0, ITOL = 4, ITASK = 4, ISTATE = 1, IOPT = 1, LIW = 0, LRW = 0, MF = 21, NNZ = 0
+    integer :: NERR = 0, quality = 0
+    character(len=128) :: chem_evol_save_filename = 'chem_evol_tmp.dat'
+    logical :: flag_chem_evol_save = .false.
+    logical :: evolT = .false., maySwitchT = .false.
+    logical :: evol_dust_size = .false.
+    double precision :: Diff2DesorRatio = 0.5D0, Edesorb_gH_bare_grain = 1.0D4, Edesorb_gH_icy_grain = 450D0, &
+                        special_gH_E_diff = 225D0
+    logical :: update_gH_params_realtime = .false., use_special_gH_mobi = .false.
+    integer :: steps_Update_gH_params = 5
+    integer :: steps_reset_solver = 9999999
+    integer :: fU_log = 6
+  end type type_chemical_evol_solver_params
+
+  type(type_chemical_evol_solver_params), save :: chemsol_params
+  namelist /chemistry_configure/ chemsol_params
+
+  interface
+    function racgpu_last_error() bind(c, name='racgpu_last_error') result(p)
+      import :: c_ptr
+      type(c_ptr) :: p
+    end function
+    function racgpu_device_count() bind(c, name='racgpu_device_count') result(n)
+      import :: c_int
+      integer(c_int) :: n
+    end function
+    function racgpu_set_device(dev) bind(c, name='racgpu_set_device') result(rc)
+      import :: c_int
+      integer(c_int), value :: dev
+      integer(c_int) :: rc
+    end function
+    function racgpu_network_load(path) bind(c, name='racgpu_network_load') result(h)
+      import :: c_ptr, c_char
+      character(kind=c_char), dimension(*), intent(in) :: path
+      type(c_ptr) :: h
+    end function
+    subroutine racgpu_network_destroy(h) bind(c, name='racgpu_network_destroy')
+      import :: c_ptr
+      type(c_ptr), value :: h
+    end subroutine
+    function racgpu_network_dims(h, nS, nR, nnzJ, nzl, nzu) bind(c, name='racgpu_network_dims') result(rc)
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h
+      integer(c_int32_t), intent(out) :: nS, nR, nnzJ, nzl, nzu
+      integer(c_int) :: rc
+    end function
+    function racgpu_species_name(h, i, buf, buflen) bind(c, name='racgpu_species_name') result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_char
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: i, buflen
+      character(kind=c_char), dimension(*), intent(out) :: buf
+      integer(c_int) :: rc
+    end function
+    function racgpu_species_index(h, name) bind(c, name='racgpu_species_index') result(i)
+      import :: c_ptr, c_int, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), dimension(*), intent(in) :: name
+      integer(c_int) :: i
+    end function
+    function racgpu_load_initial_abundances(h, path, y0) bind(c, name='racgpu_load_initial_abundances') result(rc)
+      import :: c_ptr, c_int, c_char, c_double
+      type(c_ptr), value :: h
+      character(kind=c_char), dimension(*), intent(in) :: path
+      real(c_double), dimension(*), intent(out) :: y0
+      integer(c_int) :: rc
+    end function
+    subroutine racgpu_params_default(p) bind(c, name='racgpu_params_default')
+      import :: racgpu_params_t
+      type(racgpu_params_t), intent(out) :: p
+    end subroutine
+    function racgpu_n_record(p, t0, t_max) bind(c, name='racgpu_n_record') result(n)
+      import :: racgpu_params_t, c_double, c_int
+      type(racgpu_params_t), intent(in) :: p
+      real(c_double), value :: t0, t_max
+      integer(c_int) :: n
+    end function
+    function racgpu_set_tolerances(h, p, j, d2h, rtol, atol) bind(c, name='racgpu_set_tolerances') result(rc)
+      import :: c_ptr, racgpu_params_t, c_int32_t, c_double, c_int
+      type(c_ptr), value :: h
+      type(racgpu_params_t), intent(in) :: p
+      integer(c_int32_t), value :: j
+      real(c_double), value :: d2h
+      real(c_double), dimension(*), intent(out) :: rtol, atol
+      integer(c_int) :: rc
+    end function
+    function racgpu_init_abundances(h, y0, cells, ncell, y) bind(c, name='racgpu_init_abundances') result(rc)
+      import :: c_ptr, c_double, c_int64_t, c_int
+      type(c_ptr), value :: h
+      real(c_double), dimension(*), intent(in) :: y0, cells
+      integer(c_int64_t), value :: ncell
+      real(c_double), dimension(*), intent(out) :: y
+      integer(c_int) :: rc
+    end function
+    function racgpu_rates(h, p, cells, ncell, rates) bind(c, name='racgpu_rates') result(rc)
+      import :: c_ptr, racgpu_params_t, c_double, c_int64_t, c_int
+      type(c_ptr), value :: h
+      type(racgpu_params_t), intent(in) :: p
+      real(c_double), dimension(*), intent(in) :: cells
+      integer(c_int64_t), value :: ncell
+      real(c_double), dimension(*), intent(out) :: rates
+      integer(c_int) :: rc
+    end function
+    function racgpu_solve_batch(h, p, ncell, cells, y, t_final, quality, stats, record, touts, mem) &
+        bind(c, name='racgpu_solve_batch') result(rc)
+      import :: c_ptr, racgpu_params_t, c_int64_t, c_int
+      type(c_ptr), value :: h
+      type(racgpu_params_t), intent(in) :: p
+      integer(c_int64_t), value :: ncell
+      type(c_ptr), value :: cells, y, t_final, quality, stats, record, touts
+      integer(c_int), value :: mem
+      integer(c_int) :: rc
+    end function
+    function racgpu_last_kernel_ms(h) bind(c, name='racgpu_last_kernel_ms') result(ms)
+      import :: c_ptr, c_double
+      type(c_ptr), value :: h
+      real(c_double) :: ms
+    end function
+  end interface
+
+contains
+
+  function c_string(s) result(c)
+    character(len=*), intent(in) :: s
+    character(kind=c_char), dimension(len_trim(s) + 1) :: c
+    integer :: i
+    do i = 1, len_trim(s)
+      c(i) = s(i:i)
+    end do
+    c(len_trim(s) + 1) = c_null_char
+  end function c_string
+
+  function racgpu_error_string() result(s)
+    character(len=256) :: s
+    character(kind=c_char), dimension(:), pointer :: p
+    type(c_ptr) :: cp
+    integer :: i
+    s = ''
+    cp = racgpu_last_error()
+    if (.not. c_associated(cp)) return
+    call c_f_pointer(cp, p, [256])
+    do i = 1, 256
+      if (p(i) == c_null_char) exit
+      s(i:i) = p(i)
+    end do
+  end function racgpu_error_string
+
+  ! read &chemistry_configure exactly as the reference does (src/configure.f90:28)
+  subroutine chemistry_configure_read(funit, ios)
+    integer, intent(in) :: funit
+    integer, intent(out) :: ios
+    read(funit, nml=chemistry_configure, iostat=ios)
+  end subroutine chemistry_configure_read
+
+  ! namelist values -> the C struct
+  subroutine chemsol_to_c(p)
+    type(racgpu_params_t), intent(out) :: p
+    call racgpu_params_default(p)
+    p%RTOL = chemsol_params%RTOL
+    p%ATOL = chemsol_params%ATOL
+    p%t_max = chemsol_params%t_max
+    p%dt_first_step = chemsol_params%dt_first_step
+    p%ratio_tstep = chemsol_params%ratio_tstep
+    p%max_runtime_allowed = dble(chemsol_params%max_runtime_allowed)
+    p%Diff2DesorRatio = chemsol_params%Diff2DesorRatio
+    p%special_gH_E_diff = chemsol_params%special_gH_E_diff
+    p%mxstep_per_interval = chemsol_params%mxstep_per_interval
+    p%steps_reset_solver = chemsol_params%steps_reset_solver
+    p%H2_form_use_moeq = merge(1, 0, chemsol_params%H2_form_use_moeq)
+    p%evol_dust_size = merge(1, 0, chemsol_params%evol_dust_size)
+    p%use_special_gH_mobi = merge(1, 0, chemsol_params%use_special_gH_mobi)
+    p%tol_policy_j = 1
+    p%max_steps_per_cell = 0
+  end subroutine chemsol_to_c
+
+end module racgpu
