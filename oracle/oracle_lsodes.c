@@ -311,9 +311,10 @@ void orc_lsodes_call(orc_lsodes *s, double *y, double *t, double tout, int *ista
     s->hmin = 0.0;
     for (int i = 0; i < n; i++) if (s->rtol[i] < 0.0 || s->atol[i] < 0.0) { *istate = -3; return; }
     if (*istate == 3) {
-      /* DIPREP/DPREP rerun: ordering and symbolic LU are unchanged, but the stored P is zeroed
-       * (src/opkda1.f:1492-1494), which the next DPRJS call may "reuse". */
-      memset(s->P, 0, (size_t)s->S->nnz * sizeof(double));
+      /* DIPREP/DPREP rerun: same ordering, same symbolic LU.  DPREP zeroes NNZ words at a TEMPORARY location
+       * at the far end of the work array (IPA = LENWK+1-NNZ, src/opkda1.f:1487-1494) and then moves IPA back to
+       * LREQ+1-NNZ (:1511), where the previous P still sits because the layout is the same as before; so the
+       * saved P survives an ISTATE=3 call and DPRJS may legitimately rescale it (JOK = 1). */
       s->jstart = -1;
     }
   }

@@ -2,6 +2,11 @@
 #pragma once
 #include <cstdint>
 
+// Table pointers are read by the kernels through a DevNet that itself lives in device memory; spelling out the
+// global address space keeps every table access a global_load (a pointer fetched from memory is otherwise
+// 'flat', and flat loads tie the LDS and vector-memory wait counters together).
+#define RG_GLOBAL __attribute__((address_space(1)))
+
 namespace racgpu {
 
 // flux kinds (values of racgpu::Kind in network.hpp)
@@ -32,9 +37,13 @@ struct DevNet {
   const uint8_t *jac_isdiag; // [nnzJ]
   // ---- sparse LU of the permuted species block ----
   const uint16_t *perm;      // perm[new] = old
-  const int *Lcolptr, *Ucolptr, *Pcolptr;
+  const int *Lcolptr, *Lcolend, *Ucolptr, *Ucolend, *Pcolptr; // column k of L is [Lcolptr[k], Lcolend[k]) (level-ordered storage)
   const uint16_t *Lrow, *Urow, *Prow;
   const int *Psrc;
+  // triangular-solve schedules: one packed word per stored entry, row | col<<10 | level<<20, padded to a multiple
+  // of 64 with row == col (skipped) carrying the last level
+  const uint32_t *Lrc, *Urc;
+  int nchunkL, nchunkU;
   // type-11 special indices (0-based, -1 none)
   int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;
   const uint8_t *s_tolclass; // 0 generic, 1 one of the ten special species, 2 Grain0/+/-, 3 surface species (applied in that order)

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void k_rhs(const DevNet *__restrict__ Np, const
   dev_rates(N, P, cp, rates, lane);
   for (int i = lane; i < N.nS; i += 64) v.y[i] = yin[(size_t)cell * N.nS + i];
   wave_sync();
-  dev_rhs(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], N.r_C, v.y, v.savf, lane);
+  dev_rhs(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], gptr(N.r_C), v.y, v.savf, lane);
   for (int i = lane; i < N.nS; i += 64) ydot_out[(size_t)cell * N.nS + i] = v.savf[i];
 }
 
@@ -243,6 +243,7 @@ void racgpu_network::upload() {
     for (int &v : dl) v -= 1;
     dn.dupli_ptr = up(h.dupli_ptr); dn.dupli_list = up(dl);
   }
+  w0.resize(w0.size() + 128, 0); w1.resize(w1.size() + 128, ~0ull); w2.resize(w2.size() + 128, ~0ull); // prefetch padding (kind 0 = skipped)
   dn.rhs_w0 = up(w0); dn.rhs_w1 = up(w1); dn.rhs_w2 = up(w2);
   // Jacobian gather: entries sorted by decreasing term count so that the 64 lanes of a pass do similar work
   {
@@ -271,8 +272,21 @@ void racgpu_network::upload() {
     const Symbolic &S = h.sym;
     std::vector<uint16_t> perm(S.perm.begin(), S.perm.end()), Lrow(S.Lrow.begin(), S.Lrow.end()), Urow(S.Urow.begin(), S.Urow.end()),
         Prow(S.Prow.begin(), S.Prow.end());
+    Lrow.resize(Lrow.size() + 64, 0); Urow.resize(Urow.size() + 64, 0); // the LU prefetch reads up to 64 entries past a column
     dn.perm = up(perm); dn.Lrow = up(Lrow); dn.Urow = up(Urow); dn.Prow = up(Prow);
-    dn.Lcolptr = up(S.Lcolptr); dn.Ucolptr = up(S.Ucolptr); dn.Pcolptr = up(S.Pcolptr); dn.Psrc = up(S.Psrc);
+    dn.Lcolptr = up(S.Lcolptr); dn.Lcolend = up(S.Lcolend); dn.Ucolptr = up(S.Ucolptr); dn.Ucolend = up(S.Ucolend);
+    dn.Pcolptr = up(S.Pcolptr); dn.Psrc = up(S.Psrc);
+    auto pack = [](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, int &nchunk) {
+      std::vector<uint32_t> rc(row.size());
+      for (size_t e = 0; e < row.size(); ++e) rc[e] = (uint32_t)row[e] | ((uint32_t)col[e] << 10) | ((uint32_t)lev[e] << 20);
+      const uint32_t padlev = row.empty() ? 0u : (uint32_t)lev.back();
+      rc.resize((row.size() + 63) / 64 * 64, padlev << 20); // row == col == 0: skipped
+      nchunk = (int)(rc.size() / 64);
+      rc.resize(rc.size() + 64, padlev << 20); // one spare chunk: the sweep prefetches unconditionally
+      return rc;
+    };
+    dn.Lrc = up(pack(S.Lrow, S.Lcol, S.Llev, dn.nchunkL));
+    dn.Urc = up(pack(S.Urow, S.Ucol, S.Ulev, dn.nchunkU));
   }
   dn.i_H = h.idx10[1] - 1; dn.i_E = h.idx10[2] - 1; dn.i_gH = h.i_gH - 1; dn.i_gH2 = h.i_gH2 - 1; dn.i_gH2O = h.i_gH2O - 1;
   dn.i_Grain0 = h.i_Grain0 - 1; dn.i_GrainM = h.i_GrainM - 1; dn.i_GrainP = h.i_GrainP - 1;
@@ -294,11 +308,11 @@ void racgpu_network::ensure_workspace(long slots) {
   if (slots <= ws_slots) return;
   free_ws();
   auto alloc = [&](size_t count) { void *d = nullptr; HIP_OK(hipMalloc(&d, count * sizeof(double))); ws_allocs.push_back(d); return (double *)d; };
-  ws.rates = alloc((size_t)slots * dn.nR);
+  ws.rates = alloc((size_t)slots * dn.nR + 128); // +128: the RHS prefetch of the last slot reads past nR
   ws.yh = alloc((size_t)slots * 6 * dn.npad);
   ws.P = alloc((size_t)slots * dn.nnzJ);
-  ws.L = alloc((size_t)slots * std::max(dn.nzl, 1));
-  ws.U = alloc((size_t)slots * std::max(dn.nzu, 1));
+  ws.L = alloc((size_t)slots * std::max(dn.nzl, 1) + 256); // spare: prefetches of the last slot read past nzl
+  ws.U = alloc((size_t)slots * std::max(dn.nzu, 1) + 256);
   ws.Dinv = alloc((size_t)slots * dn.npad);
   ws.rtol = alloc((size_t)slots * dn.npad);
   ws.atol = alloc((size_t)slots * dn.npad);

@@ -16,6 +16,9 @@ namespace racgpu {
 
 #define RG_DEV __device__ __forceinline__
 
+template <typename T>
+RG_DEV const RG_GLOBAL T *gptr(const T *p) { return (const RG_GLOBAL T *)p; } // table pointer -> global address space
+
 RG_DEV void wave_sync() {
   // one wave per workgroup: ordering between lanes needs only that the compiler keeps program order
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -78,11 +81,11 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
   const double sig = cell[4];
   const double cr = cell[9] / cst::CR0 * exp(-cell[11] / cst::CRattenN), xr = cell[10] / cst::CR0;
   for (int r = lane; r < N.nR; r += 64) {
-    const int it = N.r_itype[r];
-    const double A = N.r_A[r], B = N.r_B[r], C = N.r_C[r], T0 = N.r_T0[r], T1 = N.r_T1[r];
-    const int fsel = N.r_fss[r];
+    const int it = gptr(N.r_itype)[r];
+    const double A = gptr(N.r_A)[r], B = gptr(N.r_B)[r], C = gptr(N.r_C)[r], T0 = gptr(N.r_T0)[r], T1 = gptr(N.r_T1)[r];
+    const int fsel = gptr(N.r_fss)[r];
     const double fI = fsel ? cell[19 + fsel - 1] : 1.0, fS = fsel ? cell[23 + fsel - 1] : 1.0;
-    const int a = N.r_re0[r], b = N.r_re1[r];
+    const int a = gptr(N.r_re0)[r], b = gptr(N.r_re1)[r];
     double k = 0.0;
     switch (it) {
       case 5:
@@ -99,14 +102,14 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
       case 1: k = A * (cr + xr); break;
       case 2: case 20: k = A * (C / (1.0 - cell[8]) * cr + xr); break;
       case 3:
-        if (!(N.r_flags[r] & 1)) k = A * (cell[14] * exp(-C * cell[12]) * fI + cell[15] * exp(-C * cell[13]) * fS);
+        if (!(gptr(N.r_flags)[r] & 1)) k = A * (cell[14] * exp(-C * cell[12]) * fI + cell[15] * exp(-C * cell[13]) * fS);
         else k = A * (cell[14] * exp(-C * cell[12]) * fI + cell[16] * fS);
         break;
       case 21:
         if (Tgas <= 0.0) k = 0.0;
         else {
-          const double m = N.s_mass[N.r_id3[r]] * cst::mP;
-          k = sqrt(8.0 * cst::kB / cst::Pi * Tgas / m) * sig * ((N.r_flags[r] & 4) ? JNegaPosi : JChargeNeut);
+          const double m = gptr(N.s_mass)[gptr(N.r_id3)[r]] * cst::mP;
+          k = sqrt(8.0 * cst::kB / cst::Pi * Tgas / m) * sig * ((gptr(N.r_flags)[r] & 4) ? JNegaPosi : JChargeNeut);
           if (sig <= 1e-30) k = 0.0;
         }
         break;
@@ -114,31 +117,31 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
       case 0:
         if (Tgas <= 0.0) k = 0.0;
         else {
-          k = 0.5 * dev_sticking(N.s_mass[a], Tgas) * sig * sqrt(8.0 / cst::Pi * cst::kB * Tgas / cst::mP) * D2H;
+          k = 0.5 * dev_sticking(gptr(N.s_mass)[a], Tgas) * sig * sqrt(8.0 / cst::Pi * cst::kB * Tgas / cst::mP) * D2H;
           if (sig <= 1e-30) k = 0.0;
         }
         break;
       case 61:
         if (Tgas <= 0.0) k = 0.0;
         else {
-          const double m = N.s_mass[a] * cst::mP;
-          k = dev_sticking(N.s_mass[a], Tgas) * A * sig * cell[5] * sqrt(8.0 / cst::Pi * cst::kB * Tgas / m);
+          const double m = gptr(N.s_mass)[a] * cst::mP;
+          k = dev_sticking(gptr(N.s_mass)[a], Tgas) * A * sig * cell[5] * sqrt(8.0 / cst::Pi * cst::kB * Tgas / m);
           if (sig <= 1e-30) k = 0.0;
         }
         break;
       case 62:
-        k = N.s_vib[a] * (exp(-C / Tdust) + cst::CosmicDesorpPre * cr * exp(-C / cst::CosmicDesorpT));
+        k = gptr(N.s_vib)[a] * (exp(-C / Tdust) + cst::CosmicDesorpPre * cr * exp(-C / cst::CosmicDesorpT));
         if (sig <= 1e-30) k = 0.0;
         k = k * (sites * D2H);
         break;
       case 63: {
-        const double tmp = dev_mobility(P, N.s_vib[a], N.s_mass[a], N.s_Edes[a], Tdust) / sites;
+        const double tmp = dev_mobility(P, gptr(N.s_vib)[a], gptr(N.s_mass)[a], gptr(N.s_Edes)[a], Tdust) / sites;
         k = tmp / D2H * dev_branching(it, A, B, C, T0, Tdust);
-        if ((N.r_flags[r] & 2) && sig <= 1e-30) k = 0.0;
+        if ((gptr(N.r_flags)[r] & 2) && sig <= 1e-30) k = 0.0;
       } break;
       case 64:
-        k = (dev_mobility(P, N.s_vib[a], N.s_mass[a], N.s_Edes[a], Tdust) +
-             dev_mobility(P, N.s_vib[b], N.s_mass[b], N.s_Edes[b], Tdust)) / (sites * D2H) * dev_branching(it, A, B, C, T0, Tdust);
+        k = (dev_mobility(P, gptr(N.s_vib)[a], gptr(N.s_mass)[a], gptr(N.s_Edes)[a], Tdust) +
+             dev_mobility(P, gptr(N.s_vib)[b], gptr(N.s_mass)[b], gptr(N.s_Edes)[b], Tdust)) / (sites * D2H) * dev_branching(it, A, B, C, T0, Tdust);
         if (sig <= 1e-30) k = 0.0;
         break;
       case 75:
@@ -148,17 +151,17 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
       default: k = 0.0;
     }
     k = k * cst::SecPerYear;
-    if (N.r_nreac[r] == 2 && it < 60) k = k * n_gas;
+    if (gptr(N.r_nreac)[r] == 2 && it < 60) k = k * n_gas;
     rates[r] = k;
   }
   wave_sync();
   // duplicate pruning (:948-964).  Which rate gets zeroed depends only on Tgas and the temperature ranges,
   // never on the rate values, so all reactions decide at once; the only writes are zeros.
   for (int r = lane; r < N.nR; r += 64) {
-    const int q0 = N.dupli_ptr[r], q1 = N.dupli_ptr[r + 1];
+    const int q0 = gptr(N.dupli_ptr)[r], q1 = gptr(N.dupli_ptr)[r + 1];
     for (int q = q0; q < q1; ++q) {
-      const int kk = N.dupli_list[q];
-      const double v0 = fabs(N.r_T0[kk] - Tgas), v1 = fabs(N.r_T1[kk] - Tgas), v2 = fabs(N.r_T0[r] - Tgas), v3 = fabs(N.r_T1[r] - Tgas);
+      const int kk = gptr(N.dupli_list)[q];
+      const double v0 = fabs(gptr(N.r_T0)[kk] - Tgas), v1 = fabs(gptr(N.r_T1)[kk] - Tgas), v2 = fabs(gptr(N.r_T0)[r] - Tgas), v3 = fabs(gptr(N.r_T1)[r] - Tgas);
       int im = 0; double vm = v0;
       if (v1 < vm) { vm = v1; im = 1; }
       if (v2 < vm) { vm = v2; im = 2; }
@@ -182,7 +185,7 @@ RG_DEV void dev_tolerances(const DevNet &N, const DevParams &P, double d2h, doub
     default: r = fmin(P.RTOL * pow(2.0, (double)P.tol_j), 1e-3); a = fmin(P.ATOL * pow(1e2, (double)P.tol_j), 1e-15); rT = 1e-2; aT = 1e0;
   }
   for (int i = lane; i < N.nS; i += 64) {
-    const int c = N.s_tolclass[i];
+    const int c = gptr(N.s_tolclass)[i];
     double ri = r, ai = a;
     if (c == 1) { ri = fmax(P.RTOL, 1e-4); ai = fmax(P.ATOL, 1e-30); }
     else if (c == 2) { ri = 1e-4; ai = fmax(d2h * 1e-6, 1e-30); }
@@ -195,40 +198,46 @@ RG_DEV void dev_tolerances(const DevNet &N, const DevParams &P, double d2h, doub
 // f(y): chem_ode_f, reference src/disk.f90:4569-4659 (fixed-T branch).  Reaction-major, ydot scattered with
 // LDS f64 atomics (one wave owns the vector, so the result is deterministic).
 // ---------------------------------------------------------------------------------------------------------
-RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double nsite, const double *__restrict__ r_C,
+RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double nsite, const RG_GLOBAL double *__restrict__ r_C,
                     const double *y, double *ydot, int lane) {
   for (int i = lane; i < N.nS; i += 64) ydot[i] = 0.0;
   wave_sync();
+  // one-iteration-ahead software prefetch of the reaction rows and the rate vector (all padded by 64 entries)
+  const RG_GLOBAL uint64_t *W0 = gptr(N.rhs_w0), *W1 = gptr(N.rhs_w1), *W2 = gptr(N.rhs_w2);
+  uint64_t w0 = W0[lane], w1 = W1[lane], w2 = W2[lane];
+  double k = rates[lane];
   for (int r = lane; r < N.nR; r += 64) {
-    const uint64_t w0 = N.rhs_w0[r];
+    const uint64_t w0n = W0[r + 64], w1n = W1[r + 64], w2n = W2[r + 64];
+    const double kn = rates[r + 64];
     const int kind = (int)(w0 & 0xff);
-    if (kind == K_NONE_) continue;
-    const int nre = (int)((w0 >> 8) & 0xff), a = (int)((w0 >> 16) & 0xffff), b = (int)((w0 >> 32) & 0xffff);
-    const double k = rates[r], ya = y[a];
-    double f;
-    if (kind == K_TWO_) {
-      const double yb = y[b];
-      f = k * ya * yb;
-      if (ya < 0.0 && yb < 0.0) f = -f;
-    } else if (kind == K_ONE_) f = k * ya;
-    else if (kind == K_SQ_) { f = k * ya * ya; if (ya < 0.0) f = -f; }
-    else { // surface layer forms (62, 75)
-      double t1 = nsite; if (kind == K_SURF75_) t1 = t1 * r_C[r];
-      if (t1 <= 0.0) f = k;
-      else { const double t = ya / t1; f = (t <= 1e-4) ? k * t : k * (1.0 - exp(-t)); }
-    }
-    const uint64_t w1 = N.rhs_w1[r], w2 = N.rhs_w2[r];
+    if (kind != K_NONE_) {
+      const int nre = (int)((w0 >> 8) & 0xff), a = (int)((w0 >> 16) & 0xffff), b = (int)((w0 >> 32) & 0xffff);
+      const double ya = y[a];
+      double f;
+      if (kind == K_TWO_) {
+        const double yb = y[b];
+        f = k * ya * yb;
+        if (ya < 0.0 && yb < 0.0) f = -f;
+      } else if (kind == K_ONE_) f = k * ya;
+      else if (kind == K_SQ_) { f = k * ya * ya; if (ya < 0.0) f = -f; }
+      else { // surface layer forms (62, 75)
+        double t1 = nsite; if (kind == K_SURF75_) t1 = t1 * r_C[r];
+        if (t1 <= 0.0) f = k;
+        else { const double t = ya / t1; f = (t <= 1e-4) ? k * t : k * (1.0 - exp(-t)); }
+      }
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const int t = (int)(((s < 4 ? (w1 >> (16 * s)) : (w2 >> (16 * (s - 4))))) & 0xffff);
-      if (t != 0xffff) atomicAdd(&ydot[t], s < nre ? -f : f);
+      for (int s = 0; s < 7; ++s) {
+        const int t = (int)(((s < 4 ? (w1 >> (16 * s)) : (w2 >> (16 * (s - 4))))) & 0xffff);
+        if (t != 0xffff) atomicAdd(&ydot[t], s < nre ? -f : f);
+      }
     }
+    w0 = w0n; w1 = w1n; w2 = w2n; k = kn;
   }
   wave_sync();
 }
 
 // d(flux)/d(y_col) for one Jacobian term; chem_ode_jac, reference src/disk.f90:4764-4866
-RG_DEV double dev_dflux(uint64_t term, const double *__restrict__ rates, const double *__restrict__ r_C, double nsite, const double *y) {
+RG_DEV double dev_dflux(uint64_t term, const double *__restrict__ rates, const RG_GLOBAL double *__restrict__ r_C, double nsite, const double *y) {
   const int rxn = (int)(term & 0xffff), sa = (int)((term >> 16) & 0xffff), kind = (int)((term >> 32) & 0xff);
   const int flags = (int)((term >> 40) & 0xff), sb = (int)((term >> 48) & 0xffff);
   const double k = rates[rxn];
@@ -254,75 +263,152 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
                         bool add_identity, double *__restrict__ Pv, int lane) {
   wave_sync();
   for (int s = lane; s < N.jac_slots; s += 64) {
-    const int e = N.jac_order[s];
+    const int e = gptr(N.jac_order)[s];
     if (e < 0) continue;
     double sum = 0.0;
-    const int t0 = N.term_ptr[e], t1 = N.term_ptr[e + 1];
-    for (int t = t0; t < t1; ++t) sum += dev_dflux(N.terms[t], rates, N.r_C, nsite, y);
+    const int t0 = gptr(N.term_ptr)[e], t1 = gptr(N.term_ptr)[e + 1];
+    for (int t = t0; t < t1; ++t) sum += dev_dflux(gptr(N.terms)[t], rates, gptr(N.r_C), nsite, y);
     double p = sum * con;
-    if (add_identity && N.jac_isdiag[e]) p = p + 1.0;
+    if (add_identity && gptr(N.jac_isdiag)[e]) p = p + 1.0;
     Pv[e] = p;
   }
   wave_sync();
 }
 
+RG_DEV void lds_order() {
+  // Hot-loop variant of lds_sync: only pins the instruction order.  The LDS executes one wave's operations in
+  // issue order, and every access it separates goes through a run-time index into the same array, so the
+  // compiler has to keep them in program order anyway; no counter wait is inserted, which lets the next pivot's
+  // LDS read issue right behind this pivot's write instead of waiting for the write to retire.
+  __builtin_amdgcn_wave_barrier();
+}
+
+RG_DEV void lds_sync() {
+  // LDS traffic of one wave is processed in issue order, so cross-lane hand-offs through LDS only need the
+  // compiler to keep program order; no counter wait, so global prefetches stay in flight across it.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
 // Left-looking column LDU of the permuted P: P' = L * D * U, L unit lower, U unit upper, D^-1 stored.
 // w is the wave's LDS work column.  Returns false on an exactly zero pivot (DPRJS IERPJ = 1).
+// For column j the list of pivots k (rows of U(:,j)) and the extents of their L columns are fetched 64 at a
+// time into registers, and the L column of pivot t+1 is already in flight while pivot t updates w, so the
+// dependent chain per pivot is LDS-only (read w[k], fma, write w[i]).
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
                    double *__restrict__ Dinv, double *w, int lane) {
   bool ok = true;
   const int n = N.nS;
-  for (int j = 0; j < n; ++j) {
-    const int u0 = N.Ucolptr[j], u1 = N.Ucolptr[j + 1], l0 = N.Lcolptr[j], l1 = N.Lcolptr[j + 1];
-    for (int q = u0 + lane; q < u1; q += 64) w[N.Urow[q]] = 0.0;
-    for (int q = l0 + lane; q < l1; q += 64) w[N.Lrow[q]] = 0.0;
+  const RG_GLOBAL uint16_t *Lrow = gptr(N.Lrow), *Urow = gptr(N.Urow), *Prow = gptr(N.Prow);
+  const RG_GLOBAL int *Lcolptr = gptr(N.Lcolptr), *Lcolend = gptr(N.Lcolend), *Ucolptr = gptr(N.Ucolptr), *Ucolend = gptr(N.Ucolend),
+                      *Pcolptr = gptr(N.Pcolptr), *Psrc = gptr(N.Psrc);
+  for (int jc = 0; jc < n; ++jc) {
+    const int j = jc;
+    const int u0 = Ucolptr[j], u1 = Ucolend[j], lc0 = Lcolptr[j], lc1 = Lcolend[j];
+    for (int q = u0 + lane; q < u1; q += 64) w[Urow[q]] = 0.0;
+    for (int q = lc0 + lane; q < lc1; q += 64) w[Lrow[q]] = 0.0;
     if (lane == 0) w[j] = 0.0;
-    wave_sync();
-    for (int q = N.Pcolptr[j] + lane; q < N.Pcolptr[j + 1]; q += 64) w[N.Prow[q]] = Pv[N.Psrc[q]];
-    wave_sync();
-    for (int qk = u0; qk < u1; ++qk) {
-      const int k = N.Urow[qk];
-      const double t = w[k]; // = d_k * u_kj, final
-      const int c0 = N.Lcolptr[k], c1 = N.Lcolptr[k + 1];
-      for (int q = c0 + lane; q < c1; q += 64) { const int i = N.Lrow[q]; w[i] -= Lv[q] * t; }
-      wave_sync();
+    lds_sync();
+    for (int q = Pcolptr[j] + lane; q < Pcolptr[j + 1]; q += 64) w[Prow[q]] = Pv[Psrc[q]];
+    lds_sync();
+    for (int base = u0; base < u1; base += 64) {
+      const int nk = min(64, u1 - base);
+      // pivots of this batch and the extents of their L columns (lanes >= nk read in-bounds padding, unused)
+      const int kq = Urow[base + lane];
+      const int c0 = Lcolptr[kq], c1 = Lcolend[kq];
+      // Software pipeline, two pivots ahead, unrolled by three so that the three register sets rotate by name
+      // (a register-to-register rotation would have to wait for the loads it moves).  Loads are unconditional:
+      // tables and value slices are padded by 64 entries, lanes past a column's end read neighbours and ignore them.
+#define RG_LU_ISSUE(S, tt)                                                                                        \
+  {                                                                                                               \
+    const int tq_ = min((tt), nk - 1);                                                                             \
+    k##S = __builtin_amdgcn_readlane(kq, tq_); a##S = __builtin_amdgcn_readlane(c0, tq_);                          \
+    z##S = __builtin_amdgcn_readlane(c1, tq_);                                                                     \
+    i##S = Lrow[a##S + lane]; l##S = Lv[a##S + lane];                                                              \
+    if (z##S - a##S > 64) { j##S = Lrow[a##S + 64 + lane]; m##S = Lv[a##S + 64 + lane]; }                           \
+  }
+#define RG_LU_APPLY(S)                                                                                            \
+  {                                                                                                               \
+    const double tv = w[k##S]; /* = d_k * u_kj, final */                                                           \
+    if (a##S + lane < z##S) w[i##S] -= l##S * tv;                                                                  \
+    if (z##S - a##S > 64) {                                                                                        \
+      if (a##S + 64 + lane < z##S) w[j##S] -= m##S * tv;                                                           \
+      for (int q = a##S + 128 + lane; q < z##S; q += 64) { const int i = Lrow[q]; w[i] -= Lv[q] * tv; }            \
+    }                                                                                                              \
+    lds_order();                                                                                                   \
+  }
+      int k0, a0, z0, k1, a1, z1, k2, a2, z2;
+      uint16_t i0, i1, i2, j0 = 0, j1 = 0, j2 = 0; // j*, m*: entries 64..127 of a long L column
+      double l0_, l1_, l2_, m0 = 0.0, m1 = 0.0, m2 = 0.0;
+#define l0 l0_
+#define l1 l1_
+#define l2 l2_
+      RG_LU_ISSUE(0, 0)
+      RG_LU_ISSUE(1, 1)
+      for (int t = 0; t < nk; t += 3) {
+        RG_LU_ISSUE(2, t + 2)
+        RG_LU_APPLY(0)
+        if (t + 1 < nk) {
+          RG_LU_ISSUE(0, t + 3)
+          RG_LU_APPLY(1)
+          if (t + 2 < nk) {
+            RG_LU_ISSUE(1, t + 4)
+            RG_LU_APPLY(2)
+          }
+        }
+      }
+#undef l0
+#undef l1
+#undef l2
+#undef RG_LU_ISSUE
+#undef RG_LU_APPLY
     }
     const double d = w[j];
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
     if (lane == 0) Dinv[j] = dinv;
-    for (int q = u0 + lane; q < u1; q += 64) { const int k = N.Urow[q]; Uv[q] = w[k] * Dinv[k]; }
-    for (int q = l0 + lane; q < l1; q += 64) Lv[q] = w[N.Lrow[q]] * dinv;
-    wave_sync();
+    for (int q = u0 + lane; q < u1; q += 64) { const int k = Urow[q]; Uv[q] = w[k] * Dinv[k]; }
+    for (int q = lc0 + lane; q < lc1; q += 64) Lv[q] = w[Lrow[q]] * dinv;
+    wave_sync(); // L, U, Dinv of this column are read back from HBM by later columns
   }
   return ok;
+}
+
+// One triangular sweep: entries stream in level order, 64 per step; every entry does x[row] -= v * x[col].
+// Within a level the columns are independent; entries of different columns may hit the same row, hence the
+// LDS atomic.  The next 64 entries are in flight while the current ones are applied.
+RG_DEV void dev_tri_sweep(const RG_GLOBAL uint32_t *__restrict__ rc, const double *__restrict__ val, int nchunk, double *w, int lane) {
+  if (nchunk <= 0) return;
+  uint32_t r0 = rc[lane];
+  double v0 = val[lane];
+  for (int c = 0; c < nchunk; ++c) {
+    // unconditional prefetch of the next 64 entries (schedule and value slices are padded by one extra chunk)
+    const uint32_t r1 = rc[(size_t)(c + 1) * 64 + lane];
+    const double v1 = val[(size_t)(c + 1) * 64 + lane];
+    const int row = (int)(r0 & 1023u), col = (int)((r0 >> 10) & 1023u), lev = (int)(r0 >> 20);
+    const int lfirst = __builtin_amdgcn_readfirstlane(lev), llast = __builtin_amdgcn_readlane(lev, 63);
+    for (int l = lfirst; l <= llast; ++l) {
+      if (lev == l && row != col) atomicAdd(&w[row], -(v0 * w[col]));
+      lds_order();
+    }
+    r0 = r1; v0 = v1;
+  }
 }
 
 // x <- P^-1 x with the factors above; x (species order) and w are LDS vectors (DSOLSS / CDRV path 4)
 RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const double *__restrict__ Uv, const double *__restrict__ Dinv,
                       double *x, double *w, int lane) {
   const int n = N.nS;
-  wave_sync();
-  for (int i = lane; i < n; i += 64) w[i] = x[N.perm[i]];
-  wave_sync();
-  for (int k = 0; k < n; ++k) {
-    const int c0 = N.Lcolptr[k], c1 = N.Lcolptr[k + 1];
-    if (c0 == c1) continue;
-    const double xk = w[k];
-    for (int q = c0 + lane; q < c1; q += 64) { const int i = N.Lrow[q]; w[i] -= Lv[q] * xk; }
-    wave_sync();
-  }
+  lds_sync();
+  for (int i = lane; i < n; i += 64) w[i] = x[gptr(N.perm)[i]];
+  lds_sync();
+  dev_tri_sweep(gptr(N.Lrc), Lv, N.nchunkL, w, lane);
   for (int i = lane; i < n; i += 64) w[i] = w[i] * Dinv[i];
-  wave_sync();
-  for (int k = n - 1; k >= 0; --k) {
-    const int c0 = N.Ucolptr[k], c1 = N.Ucolptr[k + 1];
-    if (c0 == c1) continue;
-    const double xk = w[k];
-    for (int q = c0 + lane; q < c1; q += 64) { const int i = N.Urow[q]; w[i] -= Uv[q] * xk; }
-    wave_sync();
-  }
-  for (int i = lane; i < n; i += 64) x[N.perm[i]] = w[i];
-  wave_sync();
+  lds_sync();
+  dev_tri_sweep(gptr(N.Urc), Uv, N.nchunkU, w, lane);
+  for (int i = lane; i < n; i += 64) x[gptr(N.perm)[i]] = w[i];
+  lds_sync();
 }
 
 } // namespace racgpu

@@ -106,7 +106,7 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
       bool lost = false;
       for (int e = c.lane; e < N.nnzJ; e += 64) {
         double pij = c.Pv[e];
-        const bool dg = N.jac_isdiag[e];
+        const bool dg = gptr(N.jac_isdiag)[e];
         if (dg) { pij = pij - 1.0; if (fabs(pij) < kPsmall) lost = true; }
         pij = pij * rcon;
         if (dg) pij = pij + 1.0;
@@ -158,7 +158,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     for (int pass = 0; pass < 4; ++pass) { // label 220: re-entered after a P refresh (at most twice: rescaled P, then fresh J)
       m = 0;
       for (int i = lane; i < n; i += 64) c.y[i] = yh[i];
-      { const long long t0 = dev_clock(); dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); c.cyc_rhs += dev_clock() - t0; } s.nfe++;
+      { const long long t0 = dev_clock(); dev_rhs(N, c.rates, c.nsite, gptr(N.r_C), c.y, c.savf, lane); c.cyc_rhs += dev_clock() - t0; } s.nfe++;
       dev_mark(c, 2200 + pass);
       if (s.ipup > 0) {
         dev_prjs(N, c, s);
@@ -183,7 +183,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (m == kMaxcor) { fail410 = true; break; }
         if (m >= 2 && del > 2.0 * delp) { fail410 = true; break; }
         delp = del;
-        { const long long t0 = dev_clock(); dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); c.cyc_rhs += dev_clock() - t0; } s.nfe++;
+        { const long long t0 = dev_clock(); dev_rhs(N, c.rates, c.nsite, gptr(N.r_C), c.y, c.savf, lane); c.cyc_rhs += dev_clock() - t0; } s.nfe++;
       }
       if (converged) break;
       if (fail410 && s.jcur != 1) { s.icf = 1; s.ipup = 1; continue; }
@@ -216,7 +216,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         rh = 0.1;
         s.h = s.h * rh;
         for (int i = lane; i < n; i += 64) c.y[i] = yh[i];
-        dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); s.nfe++;
+        dev_rhs(N, c.rates, c.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe++;
         for (int i = lane; i < n; i += 64) yh[npad + i] = s.h * c.savf[i];
         s.ipup = 1; s.ialth = 5;
         if (s.nq != 1) { s.nq = 1; s.l = 2; dev_set_order(P, s); }
@@ -326,15 +326,16 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
   if (istate != 1 && s.init == 0) { istate = -3; return; }
   if (istate == 1) { s.init = 0; if (tout == t) return; }
   if (istate == 3) {
-    // DPREP reruns on ISTATE=3 and zeroes the saved P (reference src/opkda1.f:1492-1494)
-    for (int e = lane; e < N.nnzJ; e += 64) c.Pv[e] = 0.0;
+    // DIPREP/DPREP rerun on ISTATE=3 with an unchanged layout: the saved P survives (the words DPREP zeroes,
+    // reference src/opkda1.f:1487-1494, are a temporary copy at the far end of the work array), so DPRJS may
+    // rescale it.  Only the "parameters changed" flag is raised.
     s.jstart = -1;
   }
   if (istate == 1) { // Block C
     s.h0 = 0.0;
     s.tn = t; s.nst = 0; s.h = 1.0;
     for (int i = lane; i < n; i += 64) c.yh[i] = c.y[i];
-    dev_rhs(N, c.rates, c.nsite, N.r_C, c.y, c.savf, lane); s.nfe = 1;
+    dev_rhs(N, c.rates, c.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe = 1;
     for (int i = lane; i < n; i += 64) c.yh[c.npad + i] = c.savf[i];
     if (!dev_ewset(c)) { istate = -3; return; }
     for (int e = lane; e < N.nnzJ; e += 64) c.Pv[e] = 0.0;

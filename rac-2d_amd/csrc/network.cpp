@@ -357,15 +357,38 @@ void build_symbolic(HostNetwork &net) {
         rows[(size_t)i * W + w] |= m;
       }
     }
-  S.Lcolptr.assign(n + 1, 0); S.Ucolptr.assign(n + 1, 0);
-  S.Lrow.clear(); S.Urow.clear();
+  std::vector<std::vector<int>> Lc(n), Uc(n);
   for (int j = 0; j < n; ++j) {
-    for (int i = 0; i < j; ++i) if (bit(rows, i, j)) S.Urow.push_back(i);
-    S.Ucolptr[j + 1] = (int)S.Urow.size();
-    for (int i = j + 1; i < n; ++i) if (bit(rows, i, j)) S.Lrow.push_back(i);
-    S.Lcolptr[j + 1] = (int)S.Lrow.size();
+    for (int i = 0; i < j; ++i) if (bit(rows, i, j)) Uc[j].push_back(i);
+    for (int i = j + 1; i < n; ++i) if (bit(rows, i, j)) Lc[j].push_back(i);
   }
+  // dependency levels: forward solve (row i needs every column k < i with L(i,k) != 0), backward likewise
+  std::vector<int> llev(n, 0), ulev(n, 0);
+  for (int k = 0; k < n; ++k) for (int i : Lc[k]) llev[i] = std::max(llev[i], llev[k] + 1);
+  for (int k = n - 1; k >= 0; --k) for (int i : Uc[k]) ulev[i] = std::max(ulev[i], ulev[k] + 1);
+  auto lay_out = [&](const std::vector<std::vector<int>> &cols, const std::vector<int> &lev, bool descending,
+                     std::vector<int> &ptr, std::vector<int> &end, std::vector<int> &row, std::vector<int> &col,
+                     std::vector<int> &elev, int &nlev) {
+    std::vector<int> order(n);
+    for (int k = 0; k < n; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      if (lev[a] != lev[b]) return lev[a] < lev[b];
+      return descending ? a > b : a < b;
+    });
+    ptr.assign(n, 0); end.assign(n, 0); row.clear(); col.clear(); elev.clear();
+    nlev = 0;
+    for (int k : order) {
+      ptr[k] = (int)row.size();
+      for (int i : cols[k]) { row.push_back(i); col.push_back(k); elev.push_back(lev[k]); }
+      end[k] = (int)row.size();
+      if (!cols[k].empty()) nlev = std::max(nlev, lev[k] + 1);
+    }
+  };
+  lay_out(Lc, llev, false, S.Lcolptr, S.Lcolend, S.Lrow, S.Lcol, S.Llev, S.nlevL);
+  lay_out(Uc, ulev, true, S.Ucolptr, S.Ucolend, S.Urow, S.Ucol, S.Ulev, S.nlevU);
   S.nzl = (int)S.Lrow.size(); S.nzu = (int)S.Urow.size();
+  if (n > 1023 || S.nlevL > 4094 || S.nlevU > 4094)
+    throw std::runtime_error("network too large for the packed 10/10/12-bit solve schedule (n <= 1023 species)");
   // permuted columns of P
   S.Pcolptr.assign(n + 1, 0);
   std::vector<std::vector<std::pair<int, int>>> pc(n);

@@ -41,8 +41,13 @@ struct JacTerm {
 struct Symbolic { // LU structure of P = I - gamma*J on the species block, cell independent
   int n = 0;
   std::vector<int> perm, iperm;          // perm[new] = old, iperm[old] = new (0-based)
-  std::vector<int> Lcolptr, Lrow;        // strict lower, by columns of the permuted matrix, rows ascending
-  std::vector<int> Ucolptr, Urow;        // strict upper, by columns, rows ascending
+  // L (strict lower, unit diagonal) and U (strict upper, unit diagonal after D scaling) are stored by columns of
+  // the permuted matrix.  Columns are laid out in LEVEL order of the triangular solves (all columns whose x_k is
+  // final at the same dependency depth are adjacent), so a solve is one linear sweep over the value array.
+  // Column k occupies [Lcolptr[k], Lcolend[k]) with rows ascending; *lev = dependency level of each column.
+  std::vector<int> Lcolptr, Lcolend, Lrow, Lcol, Llev; // per entry: row, column, level of the column
+  std::vector<int> Ucolptr, Ucolend, Urow, Ucol, Ulev;
+  int nlevL = 0, nlevU = 0;
   std::vector<int> Pcolptr, Psrc, Prow;  // permuted columns of P: source position in the CSC value array, permuted row
   int nzl = 0, nzu = 0;
 };
