@@ -57,6 +57,7 @@ typedef struct { /* the chemsol_params namelist scalars that the path reads */
   int mxstep_per_interval, steps_reset_solver, H2_form_use_moeq;
   double Diff2DesorRatio, special_gH_E_diff;
   int use_special_gH_mobi, update_gH_params_realtime;
+  double max_runtime_allowed; /* seconds of MODELLED reference CPU time for the guards of :480-491; <= 0 = off */
 } orc_params;
 
 typedef struct { long nst, nfe, nje, nlu; int nnz, nzl, nzu; long nst_last, nfe_last, nje_last, nlu_last; } orc_stats;

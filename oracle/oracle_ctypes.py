@@ -43,6 +43,7 @@ class Params(C.Structure):
         ("mxstep_per_interval", C.c_int), ("steps_reset_solver", C.c_int), ("H2_form_use_moeq", C.c_int),
         ("Diff2DesorRatio", C.c_double), ("special_gH_E_diff", C.c_double),
         ("use_special_gH_mobi", C.c_int), ("update_gH_params_realtime", C.c_int),
+        ("max_runtime_allowed", C.c_double),
     ]
 
 

@@ -249,7 +249,7 @@ void orc_params_default(orc_params *p) { /* type defaults src/chemistry.f90:107-
   p->RTOL = 1e-4; p->ATOL = 1e-30; p->t_max = 1e6; p->dt_first_step = 1e-8; p->ratio_tstep = 1.1;
   p->mxstep_per_interval = 6000; p->steps_reset_solver = 50; p->H2_form_use_moeq = 0;
   p->Diff2DesorRatio = 0.5; p->special_gH_E_diff = 225.0; p->use_special_gH_mobi = 0;
-  p->update_gH_params_realtime = 0;
+  p->update_gH_params_realtime = 0; p->max_runtime_allowed = 60.0;
 }
 
 int orc_n_record(const orc_params *p, double t0, double t_max) { /* :1894-1899 */

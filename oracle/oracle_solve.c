@@ -2,8 +2,10 @@
  * Restates src/chemistry.f90:391-588 chem_evol_solve and :272-387 ode_solver_error_handling for the
  * fixed-T mode (evolT = maySwitchT = .false., update_gH_params_realtime = .false.), plus the cell
  * initial condition of src/disk.f90:2055-2066 and the call order of src/disk.f90:1671-1686.
- * The reference's CPU-time guards (:480-491) are non-deterministic and are not restated; with the
- * template's max_runtime_allowed = 60 s they do not fire on any fixture cell.
+ * The reference's CPU-time guards (:438, :480-491) depend on wall-clock time; they are restated on MODELLED
+ * time: per-call costs of the reference measured on one core (f 47 us, full Jacobian
+ * 10.4 ms, ~1.0 ms of LU+solves per factorisation) times the call counters.  With the template's
+ * max_runtime_allowed = 60 s they do not fire on any fixture cell.
  */
 #include "oracle.h"
 #include "oracle_lsodes.h"
@@ -45,6 +47,8 @@ int orc_evol_solve(const orc_network *net, const orc_params *p, const double *ce
   int istate = 1, nerr = 0, nerr_c = 0, qual = 0, nrr = 1, ret = 0;
   double t = t0, t_step = p->dt_first_step, tout = t + t_step;
   orc_stats acc; memset(&acc, 0, sizeof acc);
+  double rt_total = 0.0, rt_last = 1e300;
+  const double rt_max = p->max_runtime_allowed, rt_per_step = 5.0 / (double)n_record * rt_max;
   if (touts) touts[0] = t;
   if (record) memcpy(record, y, (size_t)NEQ * sizeof(double));
   for (int i = 2; i <= n_record; i++) {
@@ -53,9 +57,16 @@ int orc_evol_solve(const orc_network *net, const orc_params *p, const double *ce
     long nst0 = was_restart ? 0 : s->nst, nfe0 = was_restart ? 0 : s->nfe, nje0 = was_restart ? 0 : s->nje, nlu0 = was_restart ? 0 : s->nlu;
     orc_lsodes_call(s, y, &t, tout, &istate);
     acc.nst += s->nst - nst0; acc.nfe += s->nfe - nfe0; acc.nje += s->nje - nje0; acc.nlu += s->nlu - nlu0;
+    const double rt_this = 47e-6 * (double)(s->nfe - nfe0) + 10.4e-3 * (double)(s->nje - nje0) + 1.0e-3 * (double)(s->nlu - nlu0);
+    rt_total += rt_this;
     if (touts) touts[i - 1] = t;
     if (record) memcpy(record + (size_t)(i - 1) * NEQ, y, (size_t)NEQ * sizeof(double));
     nrr = i;
+    if (rt_max > 0.0) {
+      if (rt_this > fmax(10.0 * rt_last, 0.5 * rt_max) || rt_total > rt_max) break;
+      if (rt_this > rt_per_step) istate = 1;
+      rt_last = rt_this;
+    }
     if (t >= t_max) break;
     if (istate < 0) {
       nerr++; nerr_c++;

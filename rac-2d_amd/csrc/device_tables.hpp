@@ -53,6 +53,7 @@ struct DevParams {
   double RTOL, ATOL, t_max, dt_first_step, ratio_tstep, Diff2DesorRatio, special_gH_E_diff;
   int mxstep, steps_reset, use_special_gH_mobi, tol_j;
   long long max_steps_per_cell;
+  double max_runtime_allowed; // seconds of MODELLED reference CPU time (<= 0: guards off)
   int n_record; // for params.t_max (record layout)
   int debug_max_calls; // developer aid (env RACGPU_DEBUG_TRACE): stop a cell after this many step calls; 0 = off
   double elco[6][7];  // BDF coefficients el(i), i = 1..nq+1, per order nq = 1..5 (DCFODE, reference src/opkda1.f:146-171)

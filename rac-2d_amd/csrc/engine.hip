@@ -353,6 +353,7 @@ static DevParams to_dev(const racgpu_params *p) {
   P.mxstep = p->mxstep_per_interval; P.steps_reset = p->steps_reset_solver; P.use_special_gH_mobi = p->use_special_gH_mobi;
   P.tol_j = p->tol_policy_j > 0 ? p->tol_policy_j : 1;
   P.max_steps_per_cell = p->max_steps_per_cell;
+  P.max_runtime_allowed = p->max_runtime_allowed;
   P.n_record = racgpu_n_record(p, 0.0, p->t_max);
   if (const char *e = std::getenv("RACGPU_DEBUG_TRACE")) P.debug_max_calls = std::atoi(e);
   cfode_bdf(P);

@@ -442,6 +442,11 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
   int istate = 1, nerr = 0, nerr_c = 0, qual = 0, nrr = 1;
   double t = 0.0, t_step = P.dt_first_step, tout = t + t_step;
   long long nst_acc = 0, nfe_acc = 0, nje_acc = 0, nlu_acc = 0;
+  // Deterministic stand-in for the reference's CPU-time guards (src/chemistry.f90:438, 480-491): the time the
+  // reference would have spent is MODELLED from the call counters with its measured per-call costs on one
+  // core (f 47 us, full Jacobian 10.4 ms, LU+solves ~1.0 ms per factorisation).
+  double rt_total = 0.0, rt_last = 1e300;
+  const double rt_max = P.max_runtime_allowed, rt_per_step = 5.0 / (double)n_record * rt_max;
   const int lane = c.lane, n = c.n, neq = c.n + 1;
   if (touts) { if (lane == 0) touts[0] = t; }
   if (record) { for (int i = lane; i < n; i += 64) record[i] = c.y[i]; if (lane == 0) record[n] = c.Tgas; }
@@ -451,11 +456,18 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     const int nst0 = restart ? 0 : s.nst, nfe0 = restart ? 0 : s.nfe, nje0 = restart ? 0 : s.nje, nlu0 = restart ? 0 : s.nlu;
     dev_lsodes_call(N, P, c, s, t, tout, istate);
     nst_acc += s.nst - nst0; nfe_acc += s.nfe - nfe0; nje_acc += s.nje - nje0; nlu_acc += s.nlu - nlu0;
+    const double rt_this = 47e-6 * (double)(s.nfe - nfe0) + 10.4e-3 * (double)(s.nje - nje0) + 1.0e-3 * (double)(s.nlu - nlu0);
+    rt_total += rt_this;
     wave_sync();
     if (touts) { if (lane == 0) touts[i - 1] = t; }
     if (record) { double *rec = record + (size_t)(i - 1) * neq; for (int k = lane; k < n; k += 64) rec[k] = c.y[k]; if (lane == 0) rec[n] = c.Tgas; }
     nrr = i;
     if (P.max_steps_per_cell > 0 && nst_acc >= P.max_steps_per_cell) break; // deterministic "Premature finish"
+    if (rt_max > 0.0) { // src/chemistry.f90:482-491 on modelled time
+      if (rt_this > fmax(10.0 * rt_last, 0.5 * rt_max) || rt_total > rt_max) break;
+      if (rt_this > rt_per_step) istate = 1;
+      rt_last = rt_this;
+    }
     if (t >= t_max) break;
     if (istate < 0) {
       nerr++; nerr_c++;
