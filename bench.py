@@ -193,7 +193,8 @@ def main():
             "mean_order": qsum / max(nst, 1), "cells_with_quality_flags": int((qual != 0).sum()),
             # share of each wave's shader-clock cycles per phase (in-kernel s_memtime brackets, summed over cells)
             "phase_cycle_share": {k: float(stats[:, i].sum()) / max(float(stats[:, 8].sum()), 1.0)
-                                  for k, i in (("rhs", 9), ("jacobian", 10), ("lu", 11), ("tri_solve", 12))},
+                                  for k, i in (("rhs", 9), ("jacobian", 10), ("lu", 11), ("tri_solve", 12),
+                                               ("lu_scatter", 13), ("lu_lds_pivots", 14), ("lu_reg_pivots", 15))},
             "wave_cycles_per_cell_step": float(stats[:, 8].sum()) / max(nst, 1.0),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -72,7 +72,9 @@ typedef struct racgpu_params {
 enum { RACGPU_S_NST = 0, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_NERR, RACGPU_S_NREC_REAL,
        RACGPU_S_QSUM /* sum of the order used over accepted steps */, RACGPU_S_NCFAIL_ETFAIL,
        /* shader-clock cycles of the cell's wave, whole solve and per phase (f(y), Jacobian, LU, triangular solves) */
-       RACGPU_S_CYC_TOTAL, RACGPU_S_CYC_RHS, RACGPU_S_CYC_JAC, RACGPU_S_CYC_LU, RACGPU_S_CYC_SOLVE };
+       RACGPU_S_CYC_TOTAL, RACGPU_S_CYC_RHS, RACGPU_S_CYC_JAC, RACGPU_S_CYC_LU, RACGPU_S_CYC_SOLVE,
+       /* split of the LU cycles: column scatter, pivots applied through LDS, pivots of the dense trailing block */
+       RACGPU_S_CYC_LU_SCATTER, RACGPU_S_CYC_LU_LDS, RACGPU_S_CYC_LU_REG };
 
 /* where the caller's cell/abundance/output buffers live */
 #define RACGPU_MEM_HOST 0

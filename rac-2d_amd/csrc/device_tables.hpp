@@ -15,6 +15,7 @@ constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K
 struct DevNet {
   int nS, nR, npad;          // npad = nS rounded up to 64
   int nnzJ, nzl, nzu;
+  int ns;                    // first row/column of the dense trailing block of the LU (n - ns <= 128)
   // ---- rate coefficients (one row per reaction, original file order) ----
   const int16_t *r_itype;
   const uint16_t *r_re0, *r_re1;   // 0-based reactant species (0xFFFF none)
@@ -43,6 +44,8 @@ struct DevNet {
   // triangular-solve schedules: one packed word per stored entry, row | col<<10 | level<<20, padded to a multiple
   // of 64 with row == col (skipped) carrying the last level
   const uint32_t *Lrc, *Urc;
+  // LU pivot descriptors, one per stored U entry (pivot k of column j): k | len(L column k)<<16 | start(L column k)<<32
+  const unsigned long long *Udesc;
   int nchunkL, nchunkU;
   // type-11 special indices (0-based, -1 none)
   int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;

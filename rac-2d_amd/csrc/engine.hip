@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   for (int i = lane; i < N.nS; i += 64) v.y[i] = yin[(size_t)cell * N.nS + i];
   wave_sync();
   dev_build_P(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], v.y, -gamma, true, Pv, lane);
-  dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, lane);
+  dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.acor, lane);
   for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
   dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
   for (int i = lane; i < N.nS; i += 64) bx[(size_t)cell * N.nS + i] = v.savf[i];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
   LdsViews v = carve(lds, nlds);
   CellCtx c;
   c.y = v.y; c.savf = v.savf; c.acor = v.acor; c.ewt = v.ewt; c.wx = v.wx;
-  c.rates = W.rates + (size_t)slot * N.nR; c.yh = W.yh + (size_t)slot * 6 * N.npad; c.Pv = W.P + (size_t)slot * N.nnzJ;
+  c.rates = nullptr; c.yh = W.yh + (size_t)slot * 6 * N.npad; c.Pv = W.P + (size_t)slot * N.nnzJ;
   c.Lv = W.L + (size_t)slot * N.nzl; c.Uv = W.U + (size_t)slot * N.nzu; c.Dinv = W.Dinv + (size_t)slot * N.npad;
   c.rtol = W.rtol + (size_t)slot * N.npad; c.atol = W.atol + (size_t)slot * N.npad;
   c.lane = lane; c.n = n; c.npad = N.npad; c.inv_neq = 1.0 / (double)(n + 1);
@@ -111,13 +111,14 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
     const double *cp = cells + (size_t)cell * RACGPU_NPAR;
     const long long cyc0 = dev_clock();
     c.cyc_rhs = c.cyc_jac = c.cyc_lu = c.cyc_solve = 0;
+    c.cyc_lu_part[0] = c.cyc_lu_part[1] = c.cyc_lu_part[2] = 0; c.cyc_lu_part[3] = 0;
     c.Tgas = cp[RACGPU_P_TGAS]; c.nsite = cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES];
     const double t_max = cp[RACGPU_P_TMAX] > 0.0 ? cp[RACGPU_P_TMAX] : P.t_max;
     const int n_record = (int)ceil(log((t_max - 0.0) / P.dt_first_step * (P.ratio_tstep - 1.0) + 1.0) / log(P.ratio_tstep)) + 1;
     dev_mark(c, 1);
     dev_tolerances(N, P, cp[RACGPU_P_D2H], c.rtol, c.atol, c.rT, c.aT, lane);
     dev_mark(c, 2);
-    dev_rates(N, P, cp, c.rates, lane);
+    c.rates = W.rates + (size_t)cell * N.nR; // filled by k_rates for the whole batch just before this launch
     dev_mark(c, 3);
     for (int i = lane; i < n; i += 64) c.y[i] = yio[(size_t)cell * n + i];
     wave_sync();
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
         s[RACGPU_S_NERR] = R.nerr; s[RACGPU_S_NREC_REAL] = R.nrec_real; s[RACGPU_S_QSUM] = R.qsum; s[RACGPU_S_NCFAIL_ETFAIL] = R.nfail;
         s[RACGPU_S_CYC_TOTAL] = dev_clock() - cyc0; s[RACGPU_S_CYC_RHS] = c.cyc_rhs; s[RACGPU_S_CYC_JAC] = c.cyc_jac;
         s[RACGPU_S_CYC_LU] = c.cyc_lu; s[RACGPU_S_CYC_SOLVE] = c.cyc_solve;
+        s[13] = c.cyc_lu_part[0]; s[14] = c.cyc_lu_part[1]; s[15] = c.cyc_lu_part[2]; // finish = LU - the three
       }
     }
     dev_mark(c, 6);
@@ -158,7 +160,7 @@ struct racgpu_network {
   // workspace
   DevWork ws{};
   std::vector<void *> ws_allocs;
-  long ws_slots = 0;
+  long ws_slots = 0, ws_rate_cells = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   int cu_count = 0;
@@ -172,8 +174,8 @@ struct racgpu_network {
     return (const T *)d;
   }
   void upload();
-  void ensure_workspace(long slots);
-  void free_ws() { for (void *p : ws_allocs) (void)hipFree(p); ws_allocs.clear(); ws_slots = 0; }
+  void ensure_workspace(long slots, long rate_cells);
+  void free_ws() { for (void *p : ws_allocs) (void)hipFree(p); ws_allocs.clear(); ws_slots = 0; ws_rate_cells = 0; }
   ~racgpu_network() {
     free_ws();
     for (void *p : dev_allocs) (void)hipFree(p);
@@ -199,7 +201,7 @@ void racgpu_network::upload() {
   const HostNetwork &h = net;
   const int nS = h.nS, nR = h.nR;
   dn.nS = nS; dn.nR = nR; dn.npad = (nS + 63) / 64 * 64;
-  dn.nnzJ = (int)h.Jrow.size(); dn.nzl = h.sym.nzl; dn.nzu = h.sym.nzu;
+  dn.nnzJ = (int)h.Jrow.size(); dn.nzl = h.sym.nzl; dn.nzu = h.sym.nzu; dn.ns = h.sym.ns;
   std::vector<int16_t> itype(nR);
   std::vector<uint16_t> re0(nR), re1(nR), id3(nR, 0);
   std::vector<uint8_t> nreac(nR), fss(nR), flags(nR, 0);
@@ -285,6 +287,14 @@ void racgpu_network::upload() {
       rc.resize(rc.size() + 64, padlev << 20); // one spare chunk: the sweep prefetches unconditionally
       return rc;
     };
+    {
+      std::vector<unsigned long long> ud(S.Urow.size() + 64, 0ull);
+      for (size_t q = 0; q < S.Urow.size(); ++q) {
+        const int k = S.Urow[q];
+        ud[q] = (unsigned long long)k | ((unsigned long long)(S.Lcolend[k] - S.Lcolptr[k]) << 16) | ((unsigned long long)S.Lcolptr[k] << 32);
+      }
+      dn.Udesc = up(ud);
+    }
     dn.Lrc = up(pack(S.Lrow, S.Lcol, S.Llev, dn.nchunkL));
     dn.Urc = up(pack(S.Urow, S.Ucol, S.Ulev, dn.nchunkU));
   }
@@ -304,11 +314,12 @@ void racgpu_network::upload() {
   uploaded = true;
 }
 
-void racgpu_network::ensure_workspace(long slots) {
-  if (slots <= ws_slots) return;
+void racgpu_network::ensure_workspace(long slots, long rate_cells) {
+  if (slots <= ws_slots && rate_cells <= ws_rate_cells) return;
+  slots = std::max(slots, ws_slots); rate_cells = std::max(rate_cells, ws_rate_cells);
   free_ws();
   auto alloc = [&](size_t count) { void *d = nullptr; HIP_OK(hipMalloc(&d, count * sizeof(double))); ws_allocs.push_back(d); return (double *)d; };
-  ws.rates = alloc((size_t)slots * dn.nR + 128); // +128: the RHS prefetch of the last slot reads past nR
+  ws.rates = alloc((size_t)rate_cells * dn.nR + 128); // per CELL; +128: the RHS prefetch of the last cell reads past nR
   ws.yh = alloc((size_t)slots * 6 * dn.npad);
   ws.P = alloc((size_t)slots * dn.nnzJ);
   ws.L = alloc((size_t)slots * std::max(dn.nzl, 1) + 256); // spare: prefetches of the last slot read past nzl
@@ -320,7 +331,7 @@ void racgpu_network::ensure_workspace(long slots) {
   HIP_OK(hipMalloc(&c, 64));
   ws_allocs.push_back(c);
   ws.counter = (int *)c;
-  ws_slots = slots;
+  ws_slots = slots; ws_rate_cells = rate_cells;
 }
 
 static void cfode_bdf(DevParams &P) { // BDF method coefficients, orders 1..5 (DCFODE METH=2, reference src/opkda1.f:146-171)
@@ -531,7 +542,7 @@ int racgpu_rhs(racgpu_network *h, const racgpu_params *p, const double *cells, i
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
         dd(ydot, ncell * nS * 8, RACGPU_MEM_HOST, false);
-    h->ensure_workspace((long)ncell);
+    h->ensure_workspace((long)ncell, (long)ncell);
     hipLaunchKernelGGL(k_rhs, dim3((unsigned)ncell), dim3(64), lds_bytes(h->dn), h->stream, h->dn_dev, h->dp_dev, (const double *)dc.d, (const double *)dy.d,
                        h->ws.rates, (double *)dd.d);
     HIP_OK(hipGetLastError());
@@ -550,7 +561,7 @@ int racgpu_jac_csc(racgpu_network *h, const racgpu_params *p, const double *cell
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
         dv(vals, (size_t)ncell * h->dn.nnzJ * 8, RACGPU_MEM_HOST, false);
-    h->ensure_workspace((long)ncell);
+    h->ensure_workspace((long)ncell, (long)ncell);
     hipLaunchKernelGGL(k_jac, dim3((unsigned)ncell), dim3(64), lds_bytes(h->dn), h->stream, h->dn_dev, h->dp_dev, (const double *)dc.d, (const double *)dy.d,
                        h->ws.rates, (double *)dv.d);
     HIP_OK(hipGetLastError());
@@ -569,7 +580,7 @@ int racgpu_newton_solve(racgpu_network *h, const racgpu_params *p, const double 
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
         db(bx, ncell * nS * 8, RACGPU_MEM_HOST, true);
-    h->ensure_workspace((long)ncell);
+    h->ensure_workspace((long)ncell, (long)ncell);
     hipLaunchKernelGGL(k_newton, dim3((unsigned)ncell), dim3(64), lds_bytes(h->dn), h->stream, h->dn_dev, h->dp_dev, h->ws, (const double *)dc.d,
                        (const double *)dy.d, gamma, (double *)db.d);
     HIP_OK(hipGetLastError());
@@ -607,7 +618,8 @@ int racgpu_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell,
     const size_t lds = lds_bytes(h->dn);
     const long per_cu = std::max<long>(1, std::min<long>(8, (long)(160 * 1024 / lds)));
     const long slots = std::min<long>((long)ncell, per_cu * h->cu_count);
-    h->ensure_workspace(slots);
+    const long chunk_cells = std::max<long>(slots, std::min<long>((long)ncell, (long)(8e9 / (8.0 * h->dn.nR)))); // <= 8 GB of rates
+    h->ensure_workspace(slots, chunk_cells);
     std::vector<double> trace_host;
     DevBuf dtrace(nullptr, 0, RACGPU_MEM_HOST, false);
     h->ws.trace = nullptr;
@@ -627,11 +639,22 @@ int racgpu_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell,
       *marker_host = 0;
       HIP_OK(hipHostGetDevicePointer((void **)&h->ws.marker, marker_host, 0));
     }
-    HIP_OK(hipMemsetAsync(h->ws.counter, 0, sizeof(int), h->stream));
-    HIP_OK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(k_solve, dim3((unsigned)slots), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, (int)ncell, (const double *)dc.d, (double *)dy.d,
-                       (double *)dt.d, (int *)dq.d, (long long *)ds.d, (double *)drec.d, (double *)dto.d);
-    HIP_OK(hipGetLastError());
+    for (long c0 = 0; c0 < (long)ncell; c0 += chunk_cells) {
+      const long nc = std::min<long>(chunk_cells, (long)ncell - c0);
+      const double *cells_c = (const double *)dc.d + (size_t)c0 * RACGPU_NPAR;
+      // pass 1: rate coefficients of every cell of the chunk (one wave per cell)
+      hipLaunchKernelGGL(k_rates, dim3((unsigned)nc), dim3(64), 0, h->stream, h->dn_dev, h->dp_dev, cells_c, h->ws.rates);
+      HIP_OK(hipGetLastError());
+      // pass 2: the persistent integrator
+      HIP_OK(hipMemsetAsync(h->ws.counter, 0, sizeof(int), h->stream));
+      if (c0 == 0) HIP_OK(hipEventRecord(h->ev0, h->stream));
+      hipLaunchKernelGGL(k_solve, dim3((unsigned)std::min<long>(slots, nc)), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, (int)nc, cells_c,
+                         (double *)dy.d + (size_t)c0 * nS, dt.d ? (double *)dt.d + c0 : nullptr, dq.d ? (int *)dq.d + c0 : nullptr,
+                         ds.d ? (long long *)ds.d + (size_t)c0 * RACGPU_NSTAT : nullptr,
+                         drec.d ? (double *)drec.d + (size_t)c0 * P.n_record * (nS + 1) : nullptr,
+                         dto.d ? (double *)dto.d + (size_t)c0 * P.n_record : nullptr);
+      HIP_OK(hipGetLastError());
+    }
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     if (dbgwait) { // developer aid: watch the progress word; give up (and leave the process) instead of hanging

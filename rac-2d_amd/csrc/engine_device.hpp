@@ -88,17 +88,15 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
     const int a = gptr(N.r_re0)[r], b = gptr(N.r_re1)[r];
     double k = 0.0;
     switch (it) {
-      case 5:
-        if (Tgas <= 0.0) k = 0.0;
-        else if (C < 0.0) {
-          if (T0 > Tgas) k = A * pow(T0 / 300.0, B) * exp(-C / T0);
-          else if (T1 < Tgas) k = A * pow(T1 / 300.0, B) * exp(-C / T1);
-          else k = A * pow(T300, B) * exp(-C / Tgas);
-        } else k = A * pow(T300, B) * exp(-C / Tgas);
-        break;
-      case 6:
-        k = (T0 > Tgas || T1 < Tgas) ? 0.0 : A * pow(T300, B) * exp(-C / Tgas);
-        break;
+      case 5: case 6: {
+        // one pow and one exp for every branch of the reference's itype 5/6 selection (:681-717): which
+        // temperature enters is decided first (clamped into [Tmin,Tmax] only for negative barriers, itype 5)
+        double Te = Tgas;
+        if (it == 5 && C < 0.0) { if (T0 > Tgas) Te = T0; else if (T1 < Tgas) Te = T1; }
+        const bool zero = (it == 5) ? (Tgas <= 0.0) : (T0 > Tgas || T1 < Tgas);
+        const double base = (Te == Tgas) ? T300 : Te / 300.0;
+        k = zero ? 0.0 : A * pow(base, B) * exp(-C / Te);
+      } break;
       case 1: k = A * (cr + xr); break;
       case 2: case 20: k = A * (C / (1.0 - cell[8]) * cr + xr); break;
       case 3:
@@ -297,53 +295,58 @@ RG_DEV void lds_sync() {
 // time into registers, and the L column of pivot t+1 is already in flight while pivot t updates w, so the
 // dependent chain per pivot is LDS-only (read w[k], fma, write w[i]).
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
-                   double *__restrict__ Dinv, double *w, int lane) {
+                   double *__restrict__ Dinv, double *w, double *w2, int lane, long long *cyc = nullptr) {
+  // w, w2: two LDS work columns (w2 is only used to factor two columns of the dense trailing block at once)
   bool ok = true;
-  const int n = N.nS;
+  long long c_scatter = 0, c_rect = 0, c_dense = 0, c_fin = 0, tq = 0;
+#define RG_TICK(acc) if (cyc) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - tq; tq = now_; }
+  const int n = N.nS, ns = N.ns;
   const RG_GLOBAL uint16_t *Lrow = gptr(N.Lrow), *Urow = gptr(N.Urow), *Prow = gptr(N.Prow);
+  const RG_GLOBAL unsigned long long *Udesc = gptr(N.Udesc);
   const RG_GLOBAL int *Lcolptr = gptr(N.Lcolptr), *Lcolend = gptr(N.Lcolend), *Ucolptr = gptr(N.Ucolptr), *Ucolend = gptr(N.Ucolend),
                       *Pcolptr = gptr(N.Pcolptr), *Psrc = gptr(N.Psrc);
-  for (int jc = 0; jc < n; ++jc) {
-    const int j = jc;
-    const int u0 = Ucolptr[j], u1 = Ucolend[j], lc0 = Lcolptr[j], lc1 = Lcolend[j];
-    for (int q = u0 + lane; q < u1; q += 64) w[Urow[q]] = 0.0;
-    for (int q = lc0 + lane; q < lc1; q += 64) w[Lrow[q]] = 0.0;
-    if (lane == 0) w[j] = 0.0;
+  for (int i = lane; i < n; i += 64) { w[i] = 0.0; w2[i] = 0.0; } // work columns are kept all-zero between columns
+  lds_sync();
+  // start of the L column of every pivot of the dense trailing block, two per lane (constant over the LU)
+  const int cpA = (ns + lane < n) ? Lcolptr[ns + lane] : 0, cpB = (ns + 64 + lane < n) ? Lcolptr[ns + 64 + lane] : 0;
+  const int rowA = ns + lane, rowB = ns + 64 + lane;
+  if (cyc) tq = (long long)__builtin_readcyclecounter();
+
+  // ---- column j, part 1: scatter P(:,j) into the work column and apply the pivots k < ns through LDS -------------
+  // The pivots of a column and the extents of their L columns come as packed descriptors (k | len<<16 | a0<<32),
+  // fetched 64 at a time; L columns are software-pipelined two pivots ahead with three named register sets (a
+  // register-to-register rotation would have to wait for the loads it moves).  Loads are unconditional: tables and
+  // value slices are padded by 64 entries.  Column bases are wave-uniform, so a load costs no per-lane address math.
+  auto rect_phase = [&](int j, double *wv) {
+    const int u0 = Ucolptr[j], u1 = Ucolend[j];
+    for (int q = Pcolptr[j] + lane; q < Pcolptr[j + 1]; q += 64) wv[Prow[q]] = Pv[Psrc[q]];
     lds_sync();
-    for (int q = Pcolptr[j] + lane; q < Pcolptr[j + 1]; q += 64) w[Prow[q]] = Pv[Psrc[q]];
-    lds_sync();
-    for (int base = u0; base < u1; base += 64) {
-      const int nk = min(64, u1 - base);
-      // pivots of this batch and the extents of their L columns (lanes >= nk read in-bounds padding, unused)
-      const int kq = Urow[base + lane];
-      const int c0 = Lcolptr[kq], c1 = Lcolend[kq];
-      // Software pipeline, two pivots ahead, unrolled by three so that the three register sets rotate by name
-      // (a register-to-register rotation would have to wait for the loads it moves).  Loads are unconditional:
-      // tables and value slices are padded by 64 entries, lanes past a column's end read neighbours and ignore them.
+    RG_TICK(c_scatter)
+    const int ur = (j > ns) ? u1 - (j - ns) : u1; // pivots ns..j-1 are applied in registers (dense phase)
+    for (int base = u0; base < ur; base += 64) {
+      const int nk = min(64, ur - base);
+      const unsigned long long dq = Udesc[base + lane];
+      const int dlo = (int)(dq & 0xffffffffull), dhi = (int)(dq >> 32);
 #define RG_LU_ISSUE(S, tt)                                                                                        \
   {                                                                                                               \
     const int tq_ = min((tt), nk - 1);                                                                             \
-    k##S = __builtin_amdgcn_readlane(kq, tq_); a##S = __builtin_amdgcn_readlane(c0, tq_);                          \
-    z##S = __builtin_amdgcn_readlane(c1, tq_);                                                                     \
-    i##S = Lrow[a##S + lane]; l##S = Lv[a##S + lane];                                                              \
-    if (z##S - a##S > 64) { j##S = Lrow[a##S + 64 + lane]; m##S = Lv[a##S + 64 + lane]; }                           \
+    const int lo_ = __builtin_amdgcn_readlane(dlo, tq_);                                                           \
+    a##S = __builtin_amdgcn_readlane(dhi, tq_);                                                                    \
+    k##S = lo_ & 0xffff; z##S = lo_ >> 16; /* z = column length */                                                 \
+    const RG_GLOBAL uint16_t *rp_ = Lrow + a##S;                                                                   \
+    const double *vp_ = Lv + a##S;                                                                                 \
+    i##S = rp_[lane]; l##S = vp_[lane];                                                                            \
   }
 #define RG_LU_APPLY(S)                                                                                            \
   {                                                                                                               \
-    const double tv = w[k##S]; /* = d_k * u_kj, final */                                                           \
-    if (a##S + lane < z##S) w[i##S] -= l##S * tv;                                                                  \
-    if (z##S - a##S > 64) {                                                                                        \
-      if (a##S + 64 + lane < z##S) w[j##S] -= m##S * tv;                                                           \
-      for (int q = a##S + 128 + lane; q < z##S; q += 64) { const int i = Lrow[q]; w[i] -= Lv[q] * tv; }            \
-    }                                                                                                              \
+    const double tv = wv[k##S]; /* = d_k * u_kj, final */                                                          \
+    if (lane < z##S) wv[i##S] -= l##S * tv;                                                                        \
+    for (int q = 64 + lane; q < z##S; q += 64) { const int i = Lrow[a##S + q]; wv[i] -= Lv[a##S + q] * tv; } /* rare: > 64 rows */ \
     lds_order();                                                                                                   \
   }
       int k0, a0, z0, k1, a1, z1, k2, a2, z2;
-      uint16_t i0, i1, i2, j0 = 0, j1 = 0, j2 = 0; // j*, m*: entries 64..127 of a long L column
-      double l0_, l1_, l2_, m0 = 0.0, m1 = 0.0, m2 = 0.0;
-#define l0 l0_
-#define l1 l1_
-#define l2 l2_
+      uint16_t i0, i1, i2;
+      double l0, l1, l2;
       RG_LU_ISSUE(0, 0)
       RG_LU_ISSUE(1, 1)
       for (int t = 0; t < nk; t += 3) {
@@ -358,20 +361,92 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
           }
         }
       }
-#undef l0
-#undef l1
-#undef l2
 #undef RG_LU_ISSUE
 #undef RG_LU_APPLY
     }
-    const double d = w[j];
+    RG_TICK(c_rect)
+  };
+
+  // ---- column j, last part: pivot, scaled U and L columns to HBM, work column back to zero ------------------------
+  auto finish = [&](int j, double *wv) {
+    const int u0 = Ucolptr[j], u1 = Ucolend[j], lc0 = Lcolptr[j], lc1 = Lcolend[j];
+    const double d = wv[j];
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
-    if (lane == 0) Dinv[j] = dinv;
-    for (int q = u0 + lane; q < u1; q += 64) { const int k = Urow[q]; Uv[q] = w[k] * Dinv[k]; }
-    for (int q = lc0 + lane; q < lc1; q += 64) Lv[q] = w[Lrow[q]] * dinv;
+    if (lane == 0) { Dinv[j] = dinv; wv[j] = 0.0; }
+    for (int q = u0 + lane; q < u1; q += 64) { const int k = Urow[q]; Uv[q] = wv[k] * Dinv[k]; wv[k] = 0.0; }
+    for (int q = lc0 + lane; q < lc1; q += 64) { const int i = Lrow[q]; Lv[q] = wv[i] * dinv; wv[i] = 0.0; }
     wave_sync(); // L, U, Dinv of this column are read back from HBM by later columns
+    RG_TICK(c_fin)
+  };
+
+  auto bcast = [&](double a, double b, int kk) -> double { // value held by the lane that owns tail row ns + kk
+    union { double d; int i[2]; } s, t;
+    s.d = (kk < 64) ? a : b;
+    const int src = (kk < 64) ? kk : kk - 64;
+    t.i[0] = __builtin_amdgcn_readlane(s.i[0], src);
+    t.i[1] = __builtin_amdgcn_readlane(s.i[1], src);
+    return t.d;
+  };
+
+  int j = 0;
+  for (; j < n && j < ns; ++j) { rect_phase(j, w); RG_TICK(c_dense) finish(j, w); }
+
+  // ---- dense trailing block, two columns (j, j+1) at a time --------------------------------------------------------
+  // Rows ns+lane and ns+64+lane of both work columns live in registers.  Pivot k's multiplier is read from the lane
+  // owning row k (v_readlane); its L column is rows k+1..n-1 stored contiguously, so a lane needs entry
+  // (row - k - 1) and one load serves both columns.  No LDS inside the loop; two blocks of three pivots in flight.
+  for (; j < n; j += 2) {
+    const bool two = (j + 1 < n);
+    rect_phase(j, w);
+    if (two) rect_phase(j + 1, w2);
+    lds_sync();
+    double wA0 = (rowA < n) ? w[rowA] : 0.0, wB0 = (rowB < n) ? w[rowB] : 0.0;
+    double wA1 = (two && rowA < n) ? w2[rowA] : 0.0, wB1 = (two && rowB < n) ? w2[rowB] : 0.0;
+#define RG_DENSE_LOAD(LA, LB, kb_)                                                                               \
+  _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
+    const int k = min((kb_) + u, max(j - 1, ns)), kk = k - ns;                                                    \
+    const int cp = (kk < 64) ? __builtin_amdgcn_readlane(cpA, kk) : __builtin_amdgcn_readlane(cpB, kk - 64);      \
+    const double *col = Lv + cp - k - 1; /* col[row] = L(row, k) */                                               \
+    LA[u] = (rowA > k && rowA < n) ? col[rowA] : 0.0;                                                             \
+    LB[u] = (rowB > k && rowB < n) ? col[rowB] : 0.0;                                                             \
   }
+#define RG_DENSE_APPLY(LA, LB, kb_)                                                                              \
+  _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
+    const int k = (kb_) + u;                                                                                      \
+    if (k < j) {                                                                                                  \
+      const double t0 = bcast(wA0, wB0, k - ns), t1 = bcast(wA1, wB1, k - ns);                                    \
+      wA0 -= LA[u] * t0; wB0 -= LB[u] * t0;                                                                       \
+      wA1 -= LA[u] * t1; wB1 -= LB[u] * t1;                                                                       \
+    }                                                                                                             \
+  }
+    if (j > ns) {
+      double la0[3], lb0[3], la1[3], lb1[3];
+      RG_DENSE_LOAD(la0, lb0, ns)
+      for (int kb = ns; kb < j; kb += 6) {
+        RG_DENSE_LOAD(la1, lb1, kb + 3)
+        RG_DENSE_APPLY(la0, lb0, kb)
+        RG_DENSE_LOAD(la0, lb0, kb + 6)
+        RG_DENSE_APPLY(la1, lb1, kb + 3)
+      }
+    }
+#undef RG_DENSE_LOAD
+#undef RG_DENSE_APPLY
+    if (two) { // pivot j acts on column j+1 straight from the registers of column j
+      const double d0 = bcast(wA0, wB0, j - ns), t1 = bcast(wA1, wB1, j - ns);
+      const double dinv0 = 1.0 / d0;
+      if (rowA > j) wA1 -= (wA0 * dinv0) * t1;
+      if (rowB > j) wB1 -= (wB0 * dinv0) * t1;
+    }
+    if (rowA < n) { w[rowA] = wA0; if (two) w2[rowA] = wA1; }
+    if (rowB < n) { w[rowB] = wB0; if (two) w2[rowB] = wB1; }
+    lds_sync();
+    RG_TICK(c_dense)
+    finish(j, w);
+    if (two) finish(j + 1, w2);
+  }
+  if (cyc) { cyc[0] += c_scatter; cyc[1] += c_rect; cyc[2] += c_dense; cyc[3] += c_fin; }
+#undef RG_TICK
   return ok;
 }
 

@@ -24,6 +24,7 @@ struct CellCtx {
   double inv_neq; // 1 / (nS + 1)
   int *marker;    // developer aid: host-visible progress word, or null
   mutable long long cyc_rhs, cyc_jac, cyc_lu, cyc_solve; // shader-clock cycles spent per phase (s_memtime)
+  mutable long long cyc_lu_part[4]; // LU split: column scatter, LDS pivots, register (dense) pivots, column finish
 };
 
 RG_DEV long long dev_clock() { return (long long)__builtin_readcyclecounter(); }
@@ -123,7 +124,7 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   }
   s.nlu++; s.con0 = con; s.ierpj = 0;
   wave_sync();
-  { const long long t0 = dev_clock(); if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.lane)) s.ierpj = 1; c.cyc_lu += dev_clock() - t0; }
+  { const long long t0 = dev_clock(); if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.acor, c.lane, c.cyc_lu_part)) s.ierpj = 1; c.cyc_lu += dev_clock() - t0; }
   s.ierpj = uniform_i(wave_any(s.ierpj != 0) ? 1 : 0);
 }
 

@@ -357,6 +357,19 @@ void build_symbolic(HostNetwork &net) {
         rows[(size_t)i * W + w] |= m;
       }
     }
+  // Trailing dense block: the widest m <= 128 whose m x m corner of the filled pattern is >= 90 % dense; the few
+  // missing positions are added as explicit zeros (they stay exactly zero numerically).
+  {
+    int best = n;
+    for (int m = std::min(n, 128); m >= 8; --m) {
+      const int s0 = n - m;
+      long cnt = 0;
+      for (int i = s0; i < n; ++i) for (int j = s0; j < n; ++j) cnt += bit(rows, i, j) ? 1 : 0;
+      if ((double)cnt >= 0.90 * (double)m * (double)m) { best = s0; break; }
+    }
+    S.ns = best;
+    for (int i = S.ns; i < n; ++i) for (int j = S.ns; j < n; ++j) set(rows, i, j);
+  }
   std::vector<std::vector<int>> Lc(n), Uc(n);
   for (int j = 0; j < n; ++j) {
     for (int i = 0; i < j; ++i) if (bit(rows, i, j)) Uc[j].push_back(i);

@@ -48,6 +48,9 @@ struct Symbolic { // LU structure of P = I - gamma*J on the species block, cell 
   std::vector<int> Lcolptr, Lcolend, Lrow, Lcol, Llev; // per entry: row, column, level of the column
   std::vector<int> Ucolptr, Ucolend, Urow, Ucol, Ulev;
   int nlevL = 0, nlevU = 0;
+  // Columns/rows >= ns form a trailing block that is (made) fully dense in L and U (at most 128 wide): the LU keeps
+  // that part of its work column in registers, two rows per lane.
+  int ns = 0;
   std::vector<int> Pcolptr, Psrc, Prow;  // permuted columns of P: source position in the CSC value array, permuted row
   int nzl = 0, nzu = 0;
 };

@@ -60,8 +60,9 @@ def test_pattern_is_reference_pattern_minus_structural_zeros(racgpu, tag):
     pos = {(int(g["JA"][q]), j + 1): q for j in range(nS) for q in range(g["IA"][j] - 1, g["IA"][j + 1] - 1)}
     for key in ref - ours:
         assert g["jac0"][pos[key]] == 0.0
-    # fill of our ordering vs YSMP's on the reference pattern (IWORK(25), IWORK(26)); ours has fewer rows/cols
-    assert net.nzl + net.nzu <= 1.02 * (g["stats"][0, 5] + g["stats"][0, 6])
+    # fill of our ordering vs YSMP's on the reference pattern (IWORK(25), IWORK(26)).  Ours has fewer rows/cols but
+    # pads the trailing block (<= 128 wide, >= 90 % dense) to fully dense with explicit zeros: allow 8 %.
+    assert net.nzl + net.nzu <= 1.08 * (g["stats"][0, 5] + g["stats"][0, 6])
 
 
 def test_n_record_and_defaults(racgpu):
