@@ -49,7 +49,7 @@ def cpu_baseline(cells, y0_path, nst_gpu, max_seconds=30.0):
     build container) on a bounded sample of the same cells, one process per host core.  Falls back to the C
     restatement (kind "port").  Baseline only."""
     cores = min(os.cpu_count() or 1, 16)
-    nsample = min(len(cells), 2 * cores)
+    nsample = min(len(cells), 16 * cores)  # ~1 s per cell per core: 15-25 s of wall time
     sample = cells[:nsample]
     driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if os.path.exists(driver):
