@@ -58,6 +58,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the racgpu path)" % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own libamdhip64; a process must end up with ONE HIP runtime.  If torch is
+    # installed, load it first so that libracgpu.so binds to the runtime torch brought (loading them in the other
+    # order leaves torch unable to see the GPU).  RACGPU_NO_TORCH=1 skips this (plain ROCm runtime).
+    if not os.environ.get("RACGPU_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, dp, ip, lp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
     pp = C.POINTER(ChemsolParams)
