@@ -40,7 +40,8 @@ struct DevNet {
   const uint16_t *perm;      // perm[new] = old
   const int *Lcolptr, *Lcolend, *Ucolptr, *Ucolend, *Pcolptr; // column k of L is [Lcolptr[k], Lcolend[k]) (level-ordered storage)
   const uint16_t *Lrow, *Urow, *Prow;
-  const int *Psrc;
+  const int *Ppos;            // CSC entry -> position in the permuted-column storage of P
+  const uint8_t *Pdiag;       // [nnzJ] in storage order: 1 on the diagonal
   // triangular-solve schedules: one packed word per stored entry, row | col<<10 | level<<20, padded to a multiple
   // of 64 with row == col (skipped) carrying the last level
   const uint32_t *Lrc, *Urc;

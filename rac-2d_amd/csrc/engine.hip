@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void k_jac(const DevNet *__restrict__ Np, const
   dev_rates(N, P, cp, rates, lane);
   for (int i = lane; i < N.nS; i += 64) v.y[i] = yin[(size_t)cell * N.nS + i];
   wave_sync();
-  dev_build_P(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], v.y, 1.0, false, vals_out + (size_t)cell * N.nnzJ, lane);
+  dev_build_P<false>(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], v.y, 1.0, false, vals_out + (size_t)cell * N.nnzJ, lane);
 }
 
 __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, const double *cells, const double *yin, double gamma, double *bx) {
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   dev_rates(N, P, cp, rates, lane);
   for (int i = lane; i < N.nS; i += 64) v.y[i] = yin[(size_t)cell * N.nS + i];
   wave_sync();
-  dev_build_P(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], v.y, -gamma, true, Pv, lane);
-  dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.acor, lane);
+  dev_build_P<true>(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], v.y, -gamma, true, Pv, lane);
+  dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.acor, v.y, lane);
   for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
   dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
   for (int i = lane; i < N.nS; i += 64) bx[(size_t)cell * N.nS + i] = v.savf[i];
@@ -277,14 +277,20 @@ void racgpu_network::upload() {
     Lrow.resize(Lrow.size() + 64, 0); Urow.resize(Urow.size() + 64, 0); // the LU prefetch reads up to 64 entries past a column
     dn.perm = up(perm); dn.Lrow = up(Lrow); dn.Urow = up(Urow); dn.Prow = up(Prow);
     dn.Lcolptr = up(S.Lcolptr); dn.Lcolend = up(S.Lcolend); dn.Ucolptr = up(S.Ucolptr); dn.Ucolend = up(S.Ucolend);
-    dn.Pcolptr = up(S.Pcolptr); dn.Psrc = up(S.Psrc);
+    dn.Pcolptr = up(S.Pcolptr); dn.Ppos = up(S.Ppos);
+    {
+      std::vector<uint8_t> pd(S.Psrc.size(), 0);
+      for (int j = 0; j < nS; ++j)
+        for (int q = h.Jcolptr[j]; q < h.Jcolptr[j + 1]; ++q) if (h.Jrow[q] == j) pd[S.Ppos[q]] = 1;
+      dn.Pdiag = up(pd);
+    }
     auto pack = [](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, int &nchunk) {
       std::vector<uint32_t> rc(row.size());
       for (size_t e = 0; e < row.size(); ++e) rc[e] = (uint32_t)row[e] | ((uint32_t)col[e] << 10) | ((uint32_t)lev[e] << 20);
       const uint32_t padlev = row.empty() ? 0u : (uint32_t)lev.back();
       rc.resize((row.size() + 63) / 64 * 64, padlev << 20); // row == col == 0: skipped
       nchunk = (int)(rc.size() / 64);
-      rc.resize(rc.size() + 64, padlev << 20); // one spare chunk: the sweep prefetches unconditionally
+      rc.resize(rc.size() + 4 * 64, padlev << 20); // spare chunks: the sweep prefetches unconditionally, two chunks ahead
       return rc;
     };
     {
@@ -322,8 +328,8 @@ void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   ws.rates = alloc((size_t)rate_cells * dn.nR + 128); // per CELL; +128: the RHS prefetch of the last cell reads past nR
   ws.yh = alloc((size_t)slots * 6 * dn.npad);
   ws.P = alloc((size_t)slots * dn.nnzJ);
-  ws.L = alloc((size_t)slots * std::max(dn.nzl, 1) + 256); // spare: prefetches of the last slot read past nzl
-  ws.U = alloc((size_t)slots * std::max(dn.nzu, 1) + 256);
+  ws.L = alloc((size_t)slots * std::max(dn.nzl, 1) + 512); // spare: prefetches of the last slot read past nzl
+  ws.U = alloc((size_t)slots * std::max(dn.nzu, 1) + 512);
   ws.Dinv = alloc((size_t)slots * dn.npad);
   ws.rtol = alloc((size_t)slots * dn.npad);
   ws.atol = alloc((size_t)slots * dn.npad);

@@ -257,8 +257,10 @@ RG_DEV double dev_dflux(uint64_t term, const double *__restrict__ rates, const R
 
 // J(y) gathered entry by entry in the reference's accumulation order, then P = I + con*J
 // (DPRJS label 100-130, reference src/opkda1.f:1754-1767).  con = 1 and add_identity = false gives plain J.
+template <bool PERMUTED>
 RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, double nsite, const double *y, double con,
                         bool add_identity, double *__restrict__ Pv, int lane) {
+  // PERMUTED: write each entry at its place in the permuted-column storage the LU reads with unit stride
   wave_sync();
   for (int s = lane; s < N.jac_slots; s += 64) {
     const int e = gptr(N.jac_order)[s];
@@ -268,7 +270,7 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
     for (int t = t0; t < t1; ++t) sum += dev_dflux(gptr(N.terms)[t], rates, gptr(N.r_C), nsite, y);
     double p = sum * con;
     if (add_identity && gptr(N.jac_isdiag)[e]) p = p + 1.0;
-    Pv[e] = p;
+    Pv[PERMUTED ? gptr(N.Ppos)[e] : e] = p;
   }
   wave_sync();
 }
@@ -295,8 +297,9 @@ RG_DEV void lds_sync() {
 // time into registers, and the L column of pivot t+1 is already in flight while pivot t updates w, so the
 // dependent chain per pivot is LDS-only (read w[k], fma, write w[i]).
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
-                   double *__restrict__ Dinv, double *w, double *w2, int lane, long long *cyc = nullptr) {
-  // w, w2: two LDS work columns (w2 is only used to factor two columns of the dense trailing block at once)
+                   double *__restrict__ Dinv, double *w, double *w2, double *dl, int lane, long long *cyc = nullptr) {
+  // w: LDS work column (w2: spare LDS vector, unused);
+  // dl: LDS copy of D^-1 (the U columns are scaled by it, and a gather from LDS beats one from HBM)
   bool ok = true;
   long long c_scatter = 0, c_rect = 0, c_dense = 0, c_fin = 0, tq = 0;
 #define RG_TICK(acc) if (cyc) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - tq; tq = now_; }
@@ -304,8 +307,9 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   const RG_GLOBAL uint16_t *Lrow = gptr(N.Lrow), *Urow = gptr(N.Urow), *Prow = gptr(N.Prow);
   const RG_GLOBAL unsigned long long *Udesc = gptr(N.Udesc);
   const RG_GLOBAL int *Lcolptr = gptr(N.Lcolptr), *Lcolend = gptr(N.Lcolend), *Ucolptr = gptr(N.Ucolptr), *Ucolend = gptr(N.Ucolend),
-                      *Pcolptr = gptr(N.Pcolptr), *Psrc = gptr(N.Psrc);
-  for (int i = lane; i < n; i += 64) { w[i] = 0.0; w2[i] = 0.0; } // work columns are kept all-zero between columns
+                      *Pcolptr = gptr(N.Pcolptr);
+  (void)w2;
+  for (int i = lane; i < n; i += 64) w[i] = 0.0; // the work column is kept all-zero between columns
   lds_sync();
   // start of the L column of every pivot of the dense trailing block, two per lane (constant over the LU)
   const int cpA = (ns + lane < n) ? Lcolptr[ns + lane] : 0, cpB = (ns + 64 + lane < n) ? Lcolptr[ns + 64 + lane] : 0;
@@ -319,7 +323,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   // value slices are padded by 64 entries.  Column bases are wave-uniform, so a load costs no per-lane address math.
   auto rect_phase = [&](int j, double *wv) {
     const int u0 = Ucolptr[j], u1 = Ucolend[j];
-    for (int q = Pcolptr[j] + lane; q < Pcolptr[j + 1]; q += 64) wv[Prow[q]] = Pv[Psrc[q]];
+    for (int q = Pcolptr[j] + lane; q < Pcolptr[j + 1]; q += 64) wv[Prow[q]] = Pv[q];
     lds_sync();
     RG_TICK(c_scatter)
     const int ur = (j > ns) ? u1 - (j - ns) : u1; // pivots ns..j-1 are applied in registers (dense phase)
@@ -373,8 +377,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     const double d = wv[j];
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
-    if (lane == 0) { Dinv[j] = dinv; wv[j] = 0.0; }
-    for (int q = u0 + lane; q < u1; q += 64) { const int k = Urow[q]; Uv[q] = wv[k] * Dinv[k]; wv[k] = 0.0; }
+    if (lane == 0) { Dinv[j] = dinv; dl[j] = dinv; wv[j] = 0.0; }
+    for (int q = u0 + lane; q < u1; q += 64) { const int k = Urow[q]; Uv[q] = wv[k] * dl[k]; wv[k] = 0.0; }
     for (int q = lc0 + lane; q < lc1; q += 64) { const int i = Lrow[q]; Lv[q] = wv[i] * dinv; wv[i] = 0.0; }
     wave_sync(); // L, U, Dinv of this column are read back from HBM by later columns
     RG_TICK(c_fin)
@@ -392,17 +396,29 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   int j = 0;
   for (; j < n && j < ns; ++j) { rect_phase(j, w); RG_TICK(c_dense) finish(j, w); }
 
-  // ---- dense trailing block, two columns (j, j+1) at a time --------------------------------------------------------
-  // Rows ns+lane and ns+64+lane of both work columns live in registers.  Pivot k's multiplier is read from the lane
-  // owning row k (v_readlane); its L column is rows k+1..n-1 stored contiguously, so a lane needs entry
-  // (row - k - 1) and one load serves both columns.  No LDS inside the loop; two blocks of three pivots in flight.
-  for (; j < n; j += 2) {
-    const bool two = (j + 1 < n);
-    rect_phase(j, w);
-    if (two) rect_phase(j + 1, w2);
-    lds_sync();
-    double wA0 = (rowA < n) ? w[rowA] : 0.0, wB0 = (rowB < n) ? w[rowB] : 0.0;
-    double wA1 = (two && rowA < n) ? w2[rowA] : 0.0, wB1 = (two && rowB < n) ? w2[rowB] : 0.0;
+  // ---- dense trailing block, G columns at a time -------------------------------------------------------------------
+  // After a column's LDS pivots (k < ns) its entries in rows < ns are final and go straight to U; its tail rows
+  // (ns+lane, ns+64+lane) move to registers and stay there.  Pivot k >= ns reads its multiplier from the lane that
+  // owns row k (v_readlane) and its L column (rows k+1..n-1, contiguous) with one load that serves all G columns.
+  // Nothing of this phase touches LDS except the D^-1 copy; results are stored from registers.
+  constexpr int G = 4;
+  for (; j < n; j += G) {
+    const int ng = min(G, n - j);
+    double wA[G], wB[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      wA[c] = 0.0; wB[c] = 0.0;
+      if (c < ng) {
+        const int jc = j + c;
+        rect_phase(jc, w);
+        const int u0 = Ucolptr[jc], ur = Ucolend[jc] - (jc - ns);
+        for (int q = u0 + lane; q < ur; q += 64) { const int k = Urow[q]; Uv[q] = w[k] * dl[k]; w[k] = 0.0; }
+        if (rowA < n) { wA[c] = w[rowA]; w[rowA] = 0.0; }
+        if (rowB < n) { wB[c] = w[rowB]; w[rowB] = 0.0; }
+        lds_sync();
+        RG_TICK(c_fin)
+      }
+    }
 #define RG_DENSE_LOAD(LA, LB, kb_)                                                                               \
   _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
     const int k = min((kb_) + u, max(j - 1, ns)), kk = k - ns;                                                    \
@@ -415,9 +431,10 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
     const int k = (kb_) + u;                                                                                      \
     if (k < j) {                                                                                                  \
-      const double t0 = bcast(wA0, wB0, k - ns), t1 = bcast(wA1, wB1, k - ns);                                    \
-      wA0 -= LA[u] * t0; wB0 -= LB[u] * t0;                                                                       \
-      wA1 -= LA[u] * t1; wB1 -= LB[u] * t1;                                                                       \
+      _Pragma("unroll") for (int c = 0; c < G; ++c) {                                                            \
+        const double t = bcast(wA[c], wB[c], k - ns);                                                             \
+        wA[c] -= LA[u] * t; wB[c] -= LB[u] * t;                                                                   \
+      }                                                                                                           \
     }                                                                                                             \
   }
     if (j > ns) {
@@ -432,18 +449,35 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     }
 #undef RG_DENSE_LOAD
 #undef RG_DENSE_APPLY
-    if (two) { // pivot j acts on column j+1 straight from the registers of column j
-      const double d0 = bcast(wA0, wB0, j - ns), t1 = bcast(wA1, wB1, j - ns);
-      const double dinv0 = 1.0 / d0;
-      if (rowA > j) wA1 -= (wA0 * dinv0) * t1;
-      if (rowB > j) wB1 -= (wB0 * dinv0) * t1;
-    }
-    if (rowA < n) { w[rowA] = wA0; if (two) w2[rowA] = wA1; }
-    if (rowB < n) { w[rowB] = wB0; if (two) w2[rowB] = wB1; }
-    lds_sync();
     RG_TICK(c_dense)
-    finish(j, w);
-    if (two) finish(j + 1, w2);
+    // the G columns of the group among themselves, and the stores (from registers)
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      if (c < ng) {
+        const int jc = j + c, kk = jc - ns;
+        const double d = bcast(wA[c], wB[c], kk);
+        if (d == 0.0) ok = false;
+        const double dinv = 1.0 / d;
+        if (lane == 0) { Dinv[jc] = dinv; dl[jc] = dinv; }
+        const double lA = (rowA > jc && rowA < n) ? wA[c] * dinv : 0.0, lB = (rowB > jc && rowB < n) ? wB[c] * dinv : 0.0;
+#pragma unroll
+        for (int c2 = c + 1; c2 < G; ++c2) {
+          if (c2 < ng) {
+            const double t = bcast(wA[c2], wB[c2], kk);
+            wA[c2] -= lA * t; wB[c2] -= lB * t;
+          }
+        }
+        lds_sync(); // dl[jc] is read below by the lanes of later columns
+        double *Ut = Uv + (Ucolend[jc] - kk) - ns; // Ut[row] = U(row, jc) for ns <= row < jc
+        double *Lt = Lv + Lcolptr[jc] - jc - 1;    // Lt[row] = L(row, jc) for row > jc
+        if (rowA < jc) Ut[rowA] = wA[c] * dl[rowA];
+        else if (rowA > jc && rowA < n) Lt[rowA] = lA;
+        if (rowB < jc) Ut[rowB] = wB[c] * dl[rowB];
+        else if (rowB > jc && rowB < n) Lt[rowB] = lB;
+      }
+    }
+    wave_sync(); // L, U, Dinv of these columns are read back from HBM by later columns
+    RG_TICK(c_fin)
   }
   if (cyc) { cyc[0] += c_scatter; cyc[1] += c_rect; cyc[2] += c_dense; cyc[3] += c_fin; }
 #undef RG_TICK
@@ -455,20 +489,36 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 // LDS atomic.  The next 64 entries are in flight while the current ones are applied.
 RG_DEV void dev_tri_sweep(const RG_GLOBAL uint32_t *__restrict__ rc, const double *__restrict__ val, int nchunk, double *w, int lane) {
   if (nchunk <= 0) return;
-  uint32_t r0 = rc[lane];
-  double v0 = val[lane];
-  for (int c = 0; c < nchunk; ++c) {
-    // unconditional prefetch of the next 64 entries (schedule and value slices are padded by one extra chunk)
-    const uint32_t r1 = rc[(size_t)(c + 1) * 64 + lane];
-    const double v1 = val[(size_t)(c + 1) * 64 + lane];
-    const int row = (int)(r0 & 1023u), col = (int)((r0 >> 10) & 1023u), lev = (int)(r0 >> 20);
-    const int lfirst = __builtin_amdgcn_readfirstlane(lev), llast = __builtin_amdgcn_readlane(lev, 63);
-    for (int l = lfirst; l <= llast; ++l) {
-      if (lev == l && row != col) atomicAdd(&w[row], -(v0 * w[col]));
-      lds_order();
-    }
-    r0 = r1; v0 = v1;
+  // three named register sets, two chunks ahead (same scheme as the LU pivots); the schedule is padded by four
+  // chunks and the value slices by 256 entries so every prefetch is unconditional
+#define RG_TS_LOAD(S, cc) { r##S = rc[(size_t)(cc) * 64 + lane]; v##S = val[(size_t)(cc) * 64 + lane]; }
+#define RG_TS_APPLY(S)                                                                                            \
+  {                                                                                                               \
+    const int row = (int)(r##S & 1023u), col = (int)((r##S >> 10) & 1023u), lev = (int)(r##S >> 20);               \
+    const int lfirst = __builtin_amdgcn_readfirstlane(lev), llast = __builtin_amdgcn_readlane(lev, 63);            \
+    for (int l = lfirst; l <= llast; ++l) {                                                                        \
+      if (lev == l && row != col) atomicAdd(&w[row], -(v##S * w[col]));                                            \
+      lds_order();                                                                                                 \
+    }                                                                                                              \
   }
+  uint32_t r0, r1, r2;
+  double v0, v1, v2;
+  RG_TS_LOAD(0, 0)
+  RG_TS_LOAD(1, 1)
+  for (int c = 0; c < nchunk; c += 3) {
+    RG_TS_LOAD(2, c + 2)
+    RG_TS_APPLY(0)
+    if (c + 1 < nchunk) {
+      RG_TS_LOAD(0, c + 3)
+      RG_TS_APPLY(1)
+      if (c + 2 < nchunk) {
+        RG_TS_LOAD(1, c + 4)
+        RG_TS_APPLY(2)
+      }
+    }
+  }
+#undef RG_TS_LOAD
+#undef RG_TS_APPLY
 }
 
 // x <- P^-1 x with the factors above; x (species order) and w are LDS vectors (DSOLSS / CDRV path 4)

@@ -107,7 +107,7 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
       bool lost = false;
       for (int e = c.lane; e < N.nnzJ; e += 64) {
         double pij = c.Pv[e];
-        const bool dg = gptr(N.jac_isdiag)[e];
+        const bool dg = gptr(N.Pdiag)[e]; // P is stored in permuted-column order
         if (dg) { pij = pij - 1.0; if (fabs(pij) < kPsmall) lost = true; }
         pij = pij * rcon;
         if (dg) pij = pij + 1.0;
@@ -119,12 +119,12 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   if (!jok) {
     s.jcur = 1; s.nje++; s.nslj = s.nst; s.iplost = 0; s.conmin = fabs(con);
     dev_mark(c, 3000);
-    { const long long t0 = dev_clock(); dev_build_P(N, c.rates, c.nsite, c.y, con, true, c.Pv, c.lane); c.cyc_jac += dev_clock() - t0; }
+    { const long long t0 = dev_clock(); dev_build_P<true>(N, c.rates, c.nsite, c.y, con, true, c.Pv, c.lane); c.cyc_jac += dev_clock() - t0; }
     dev_mark(c, 3001);
   }
   s.nlu++; s.con0 = con; s.ierpj = 0;
   wave_sync();
-  { const long long t0 = dev_clock(); if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.acor, c.lane, c.cyc_lu_part)) s.ierpj = 1; c.cyc_lu += dev_clock() - t0; }
+  { const long long t0 = dev_clock(); if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.acor, c.y, c.lane, c.cyc_lu_part)) s.ierpj = 1; c.cyc_lu += dev_clock() - t0; }
   s.ierpj = uniform_i(wave_any(s.ierpj != 0) ? 1 : 0);
 }
 

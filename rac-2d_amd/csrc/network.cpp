@@ -413,6 +413,8 @@ void build_symbolic(HostNetwork &net) {
     for (auto &e : pc[j]) { S.Prow.push_back(e.first); S.Psrc.push_back(e.second); }
     S.Pcolptr[j + 1] = (int)S.Psrc.size();
   }
+  S.Ppos.assign(S.Psrc.size(), 0);
+  for (size_t q = 0; q < S.Psrc.size(); ++q) S.Ppos[S.Psrc[q]] = (int)q;
 }
 
 } // namespace racgpu

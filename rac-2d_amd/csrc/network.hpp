@@ -51,7 +51,9 @@ struct Symbolic { // LU structure of P = I - gamma*J on the species block, cell 
   // Columns/rows >= ns form a trailing block that is (made) fully dense in L and U (at most 128 wide): the LU keeps
   // that part of its work column in registers, two rows per lane.
   int ns = 0;
-  std::vector<int> Pcolptr, Psrc, Prow;  // permuted columns of P: source position in the CSC value array, permuted row
+  // P is STORED in permuted-column order (column j' = perm^-1 of species column, rows ascending): Pcolptr/Prow
+  // describe that storage; Psrc[q] = CSC entry held at position q, Ppos = its inverse
+  std::vector<int> Pcolptr, Psrc, Prow, Ppos;
   int nzl = 0, nzu = 0;
 };
 
