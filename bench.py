@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=10000, help="cells per GPU (default: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hints", action="store_true", help="take cells in queue order in every pass (no cost feedback)")
     args = ap.parse_args()
 
     import torch
@@ -146,14 +147,23 @@ def main():
             dist.all_gather_into_tensor(gathered, y_d)  # the path's single exchange: RCCL over xGMI
         torch.cuda.synchronize(dev)
         kernel_ms.append(net.last_kernel_ms())
+        if not args.no_hints:
+            # cost feedback, as between two global iterations of the disk model: the cycles each cell took in this pass
+            # order the next pass (costliest first).  Part of the pass, so it is inside the timed region.
+            net.set_cost_hints(stats_d[:, 8].cpu().numpy().astype(np.float64))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    first_pass_s = None
+    for w in range(args.warmup):
+        tw = time.perf_counter()
         one_pass()
+        if w == 0:
+            first_pass_s = time.perf_counter() - tw  # the only pass that runs without cost hints
+    hinted = (not args.no_hints) and args.warmup > 0
     kernel_ms.clear()
     barrier()
     t0 = time.perf_counter()
@@ -184,7 +194,12 @@ def main():
             "config": {"workload": "configs[1]: %d synthetic cells per GPU (log-uniform T in [10,3000] K, n_H in [1e3,1e12] cm^-3), "
                                    "rate06 no-grain network (%s: %d species, %d reactions), %s, t_max=1e6 yr, RTOL=1e-4, "
                                    "steps_reset_solver=50" % (ncell, NETWORK, nS, net.nReactions, INITIAL),
-                       "cells_per_gpu": ncell, "parallelism": "cells sharded over %d GPU(s), one RCCL all-gather at output" % world},
+                       "cells_per_gpu": ncell, "parallelism": "cells sharded over %d GPU(s), one RCCL all-gather at output" % world,
+                       "scheduling": ("costliest-first from the previous pass's per-cell cycle counts (racgpu_set_cost_hints)" if hinted
+                                      else "queue order (no previous pass to take cost hints from)"),
+                       # rank 0's first warm-up pass runs in queue order: its rate is the no-feedback figure
+                       "queue_order_first_pass": ({"ms": 1e3 * first_pass_s, "cell_steps_per_s_rank0": float(stats[:, 0].sum()) / first_pass_s}
+                                                  if (first_pass_s and hinted) else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_solve", "kernel_ms": kms, "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_cell_step": abytes / max(nst, 1.0)},

@@ -136,6 +136,13 @@ int racgpu_newton_solve(racgpu_network *, const racgpu_params *, const double *c
  */
 int racgpu_solve_batch(racgpu_network *, const racgpu_params *, int64_t ncell, const double *cells, double *y,
                        double *t_final, int32_t *quality, int64_t *stats, double *record, double *touts, int mem);
+/* Scheduling hint for the following racgpu_solve_batch calls (an extension: the reference has no counterpart; its
+ * cell loop, src/disk.f90:864-1010, takes cells in grid order).  cost[ncell] (host memory) is any per-cell measure
+ * of expected work, e.g. the step count RACGPU_S_NST or the cycle count RACGPU_S_CYC_TOTAL the same cell needed in
+ * the previous global iteration of the disk model; waves then take cells in order of decreasing cost, so the few
+ * cells that need many times the median work start first instead of last.  Results do not depend on the order.
+ * The hint applies while ncell matches; cost == NULL or ncell == 0 clears it. */
+int racgpu_set_cost_hints(racgpu_network *, const double *cost, int64_t ncell);
 /* bytes of device workspace racgpu_solve_batch keeps per cell (grows the handle's workspace on demand) */
 int64_t racgpu_workspace_bytes_per_cell(const racgpu_network *);
 /* HIP-event time of the last racgpu_solve_batch kernel on its stream, milliseconds (-1 if none) */

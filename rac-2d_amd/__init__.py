@@ -19,7 +19,7 @@ from . import cells  # noqa: F401  (synthetic cell records)
 from .cells import NPAR
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libracgpu.so")
+LIB_PATH = os.environ.get("RACGPU_LIB") or os.path.join(_HERE, "libracgpu.so")  # RACGPU_LIB: developer builds
 NSTAT = 16
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "racgpu_species_attrs", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
-    "racgpu_solve_batch", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
+    "racgpu_solve_batch", "racgpu_set_cost_hints", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
 ]
 
 
@@ -93,6 +93,8 @@ def lib():
     L.racgpu_solve_batch.argtypes = [vp, pp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.racgpu_workspace_bytes_per_cell.restype = C.c_int64
     L.racgpu_workspace_bytes_per_cell.argtypes = [vp]
+    L.racgpu_set_cost_hints.restype = C.c_int
+    L.racgpu_set_cost_hints.argtypes = [vp, dp, C.c_int64]
     L.racgpu_last_kernel_ms.restype = C.c_double
     L.racgpu_last_kernel_ms.argtypes = [vp]
     _lib = L
@@ -250,6 +252,15 @@ class Network:
         """Same, on device pointers (e.g. torch tensors' data_ptr()); asynchronous on the handle's stream."""
         _check(lib().racgpu_solve_batch(self._h, C.byref(params), ncell, cells_ptr, y_ptr, t_final_ptr, quality_ptr,
                                         stats_ptr, None, None, MEM_DEVICE))
+
+    def set_cost_hints(self, cost=None):
+        """Per-cell expected work (e.g. stats[:, S_NST] of the previous global iteration) for the following
+        evol_solve_batch calls: waves take the costliest cells first.  None clears the hint."""
+        if cost is None:
+            _check(lib().racgpu_set_cost_hints(self._h, None, 0))
+            return
+        cost = np.ascontiguousarray(cost, dtype=np.float64).ravel()
+        _check(lib().racgpu_set_cost_hints(self._h, cost.ctypes.data_as(C.POINTER(C.c_double)), cost.size))
 
     def last_kernel_ms(self):
         return lib().racgpu_last_kernel_ms(self._h)

@@ -12,6 +12,11 @@ namespace racgpu {
 // flux kinds (values of racgpu::Kind in network.hpp)
 constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K_SQ_ = 5;
 
+// extents of column j in the U, L and P storage; ur = end of the U entries with rows < ns (the pivots applied through
+// LDS); [d0, d1) = the column's slice of the pivot descriptor stream
+struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, pad[7]; };
+constexpr int kLuDepth = 6; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
+
 struct DevNet {
   int nS, nR, npad;          // npad = nS rounded up to 64
   int nnzJ, nzl, nzu;
@@ -45,8 +50,11 @@ struct DevNet {
   // triangular-solve schedules: one packed word per stored entry, row | col<<10 | level<<20, padded to a multiple
   // of 64 with row == col (skipped) carrying the last level
   const uint32_t *Lrc, *Urc;
-  // LU pivot descriptors, one per stored U entry (pivot k of column j): k | len(L column k)<<16 | start(L column k)<<32
+  // LU pivot descriptors, per column j one slice [d0, d1): for every pivot k < ns of the column, in U storage order,
+  // k | len<<16 | (1<<30 if the pivot opens a new level within column j) | start<<32, where [start, start+len) is
+  // (a piece of at most 64 rows of) L column k; slices are padded with null descriptors (len 0)
   const unsigned long long *Udesc;
+  const LuCol *lucol;        // [nS+1] per-column extents for the LU (entry nS repeats nS-1: the column prefetch reads one ahead)
   int nchunkL, nchunkU;
   // type-11 special indices (0-based, -1 none)
   int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(64) void k_jac(const DevNet *__restrict__ Np, const
   dev_build_P<false>(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], v.y, 1.0, false, vals_out + (size_t)cell * N.nnzJ, lane);
 }
 
-__global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, const double *cells, const double *yin, double gamma, double *bx) {
+__global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, const double *cells, const double *yin, double gamma, double *bx,
+                                               int repeat, long long *cyc_out) {
   const DevNet &N = *Np; const DevParams &P = *Pp;
   extern __shared__ double lds[];
   const int cell = blockIdx.x, lane = threadIdx.x, nlds = (N.nS + 1) & ~1;
@@ -80,17 +81,30 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   for (int i = lane; i < N.nS; i += 64) v.y[i] = yin[(size_t)cell * N.nS + i];
   wave_sync();
   dev_build_P<true>(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], v.y, -gamma, true, Pv, lane);
-  dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.acor, v.y, lane);
-  for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
-  dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
+  // repeat > 1 (developer aid, RACGPU_DEBUG_REPEAT): the same factorisation and solve again and again, with the
+  // cycle counts of the LU parts and of the solve written out per cell
+  long long cyc[4] = {0, 0, 0, 0}, c_lu = 0, c_solve = 0;
+  for (int r = 0; r < repeat; ++r) {
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.acor, v.y, lane, cyc_out ? cyc : nullptr);
+    const long long t1 = (long long)__builtin_readcyclecounter();
+    for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
+    dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
+    c_lu += t1 - t0; c_solve += (long long)__builtin_readcyclecounter() - t1;
+  }
   for (int i = lane; i < N.nS; i += 64) bx[(size_t)cell * N.nS + i] = v.savf[i];
+  if (cyc_out && lane == 0) {
+    long long *o = cyc_out + (size_t)cell * 8;
+    o[0] = c_lu; o[1] = c_solve; o[2] = cyc[0]; o[3] = cyc[1]; o[4] = cyc[2]; o[5] = cyc[3];
+  }
 }
 
 // The hot path.  Persistent: each wave pulls cells from a queue until it is empty; its workspace is per wave
 // (slot), not per cell, so the HBM footprint is nslots * ~0.4 MB whatever the batch size.
 __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, int ncell, const double *__restrict__ cells,
                                               double *__restrict__ yio, double *__restrict__ t_final, int *__restrict__ quality,
-                                              long long *__restrict__ stats, double *__restrict__ record, double *__restrict__ touts) {
+                                              long long *__restrict__ stats, double *__restrict__ record, double *__restrict__ touts,
+                                              const int *__restrict__ order) {
   extern __shared__ double lds[];
   const DevNet &N = *Np; const DevParams &P = *Pp;
   const int lane = threadIdx.x, slot = blockIdx.x, n = N.nS, nlds = (n + 1) & ~1;
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
     cell = uniform_i(cell);
     dev_mark(c, 10 + cell);
     if (cell >= ncell) break;
+    if (order) cell = order[cell]; // longest-expected-first schedule (racgpu_set_cost_hints)
     const double *cp = cells + (size_t)cell * RACGPU_NPAR;
     const long long cyc0 = dev_clock();
     c.cyc_rhs = c.cyc_jac = c.cyc_lu = c.cyc_solve = 0;
@@ -162,6 +177,8 @@ struct racgpu_network {
   std::vector<void *> ws_allocs;
   long ws_slots = 0, ws_rate_cells = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<double> cost_hints; // racgpu_set_cost_hints
+  int *order_dev = nullptr; long order_cap = 0;
   bool timed = false;
   int cu_count = 0;
 
@@ -178,6 +195,7 @@ struct racgpu_network {
   void free_ws() { for (void *p : ws_allocs) (void)hipFree(p); ws_allocs.clear(); ws_slots = 0; ws_rate_cells = 0; }
   ~racgpu_network() {
     free_ws();
+    if (order_dev) (void)hipFree(order_dev);
     for (void *p : dev_allocs) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -275,6 +293,7 @@ void racgpu_network::upload() {
     std::vector<uint16_t> perm(S.perm.begin(), S.perm.end()), Lrow(S.Lrow.begin(), S.Lrow.end()), Urow(S.Urow.begin(), S.Urow.end()),
         Prow(S.Prow.begin(), S.Prow.end());
     Lrow.resize(Lrow.size() + 64, 0); Urow.resize(Urow.size() + 64, 0); // the LU prefetch reads up to 64 entries past a column
+    Prow.resize(Prow.size() + 64, 0);
     dn.perm = up(perm); dn.Lrow = up(Lrow); dn.Urow = up(Urow); dn.Prow = up(Prow);
     dn.Lcolptr = up(S.Lcolptr); dn.Lcolend = up(S.Lcolend); dn.Ucolptr = up(S.Ucolptr); dn.Ucolend = up(S.Ucolend);
     dn.Pcolptr = up(S.Pcolptr); dn.Ppos = up(S.Ppos);
@@ -290,16 +309,32 @@ void racgpu_network::upload() {
       const uint32_t padlev = row.empty() ? 0u : (uint32_t)lev.back();
       rc.resize((row.size() + 63) / 64 * 64, padlev << 20); // row == col == 0: skipped
       nchunk = (int)(rc.size() / 64);
-      rc.resize(rc.size() + 4 * 64, padlev << 20); // spare chunks: the sweep prefetches unconditionally, two chunks ahead
+      rc.resize(rc.size() + 16 * 64, padlev << 20); // spare chunks: the sweep prefetches unconditionally, up to 15 chunks ahead
       return rc;
     };
     {
-      std::vector<unsigned long long> ud(S.Urow.size() + 64, 0ull);
-      for (size_t q = 0; q < S.Urow.size(); ++q) {
-        const int k = S.Urow[q];
-        ud[q] = (unsigned long long)k | ((unsigned long long)(S.Lcolend[k] - S.Lcolptr[k]) << 16) | ((unsigned long long)S.Lcolptr[k] << 32);
+      std::vector<unsigned long long> ud;
+      std::vector<LuCol> lc(nS + 1);
+      for (int j = 0; j < nS; ++j) {
+        const int ur = (j > S.ns) ? S.Ucolend[j] - (j - S.ns) : S.Ucolend[j]; // pivots ns..j-1 are applied in registers
+        LuCol c{};
+        c.u0 = S.Ucolptr[j]; c.u1 = S.Ucolend[j]; c.lc0 = S.Lcolptr[j]; c.lc1 = S.Lcolend[j]; c.p0 = S.Pcolptr[j]; c.p1 = S.Pcolptr[j + 1];
+        c.ur = ur; c.d0 = (int)ud.size();
+        for (int q = S.Ucolptr[j]; q < ur; ++q) {
+          const int k = S.Urow[q];
+          const int len = S.Lcolend[k] - S.Lcolptr[k];
+          for (int off = 0; off < std::max(len, 1); off += 64) // L columns longer than 64 rows: one descriptor per 64 rows
+            ud.push_back((unsigned long long)k | ((unsigned long long)std::min(64, len - off) << 16) |
+                         ((unsigned long long)((S.Ugrp[q] && off == 0) ? 1 : 0) << 30) | ((unsigned long long)(S.Lcolptr[k] + off) << 32));
+        }
+        while (ud.size() % kLuDepth) ud.push_back(0ull);
+        c.d1 = (int)ud.size();
+        lc[j] = c;
       }
+      ud.resize(ud.size() + 64, 0ull);
       dn.Udesc = up(ud);
+      lc[nS] = nS > 0 ? lc[nS - 1] : LuCol{};
+      dn.lucol = up(lc);
     }
     dn.Lrc = up(pack(S.Lrow, S.Lcol, S.Llev, dn.nchunkL));
     dn.Urc = up(pack(S.Urow, S.Ucol, S.Ulev, dn.nchunkU));
@@ -327,9 +362,9 @@ void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   auto alloc = [&](size_t count) { void *d = nullptr; HIP_OK(hipMalloc(&d, count * sizeof(double))); ws_allocs.push_back(d); return (double *)d; };
   ws.rates = alloc((size_t)rate_cells * dn.nR + 128); // per CELL; +128: the RHS prefetch of the last cell reads past nR
   ws.yh = alloc((size_t)slots * 6 * dn.npad);
-  ws.P = alloc((size_t)slots * dn.nnzJ);
-  ws.L = alloc((size_t)slots * std::max(dn.nzl, 1) + 512); // spare: prefetches of the last slot read past nzl
-  ws.U = alloc((size_t)slots * std::max(dn.nzu, 1) + 512);
+  ws.P = alloc((size_t)slots * dn.nnzJ + 64); // spare: the LU's column prefetch reads up to 63 entries past a column
+  ws.L = alloc((size_t)slots * std::max(dn.nzl, 1) + 2048); // spare: prefetches of the last slot read past nzl
+  ws.U = alloc((size_t)slots * std::max(dn.nzu, 1) + 2048);
   ws.Dinv = alloc((size_t)slots * dn.npad);
   ws.rtol = alloc((size_t)slots * dn.npad);
   ws.atol = alloc((size_t)slots * dn.npad);
@@ -587,12 +622,32 @@ int racgpu_newton_solve(racgpu_network *h, const racgpu_params *p, const double 
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
         db(bx, ncell * nS * 8, RACGPU_MEM_HOST, true);
     h->ensure_workspace((long)ncell, (long)ncell);
+    const char *rep_env = getenv("RACGPU_DEBUG_REPEAT"); // developer aid: time the factorisation + solve in isolation
+    const int repeat = rep_env ? std::max(1, atoi(rep_env)) : 1;
+    long long *cyc_dev = nullptr;
+    if (rep_env) { HIP_OK(hipMalloc((void **)&cyc_dev, (size_t)ncell * 8 * sizeof(long long))); HIP_OK(hipMemset(cyc_dev, 0, (size_t)ncell * 8 * sizeof(long long))); }
     hipLaunchKernelGGL(k_newton, dim3((unsigned)ncell), dim3(64), lds_bytes(h->dn), h->stream, h->dn_dev, h->dp_dev, h->ws, (const double *)dc.d,
-                       (const double *)dy.d, gamma, (double *)db.d);
+                       (const double *)dy.d, gamma, (double *)db.d, repeat, cyc_dev);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(h->stream));
+    if (cyc_dev) {
+      std::vector<long long> cy((size_t)ncell * 8);
+      HIP_OK(hipMemcpy(cy.data(), cyc_dev, cy.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      (void)hipFree(cyc_dev);
+      double a[6] = {0, 0, 0, 0, 0, 0};
+      for (int64_t c = 0; c < ncell; ++c) for (int k = 0; k < 6; ++k) a[k] += (double)cy[(size_t)c * 8 + k];
+      const double den = (double)ncell * repeat;
+      fprintf(stderr, "[racgpu debug] %lld cells x %d: cycles per LU %.0f (scatter %.0f, lds pivots %.0f, register pivots %.0f, finish %.0f), per solve %.0f\n",
+              (long long)ncell, repeat, a[0] / den, a[2] / den, a[3] / den, a[4] / den, a[5] / den, a[1] / den);
+    }
     db.copy_out();
   });
+}
+
+int racgpu_set_cost_hints(racgpu_network *h, const double *cost, int64_t ncell) {
+  if (!h) return fail("null network");
+  if (!cost || ncell <= 0) { h->cost_hints.clear(); return 0; }
+  return guarded([&] { h->cost_hints.assign(cost, cost + ncell); });
 }
 
 int64_t racgpu_workspace_bytes_per_cell(const racgpu_network *h) {
@@ -645,6 +700,24 @@ int racgpu_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell,
       *marker_host = 0;
       HIP_OK(hipHostGetDevicePointer((void **)&h->ws.marker, marker_host, 0));
     }
+    // optional longest-expected-first order, per chunk (indices relative to the chunk)
+    const bool hinted = (int64_t)h->cost_hints.size() == ncell;
+    if (hinted) {
+      if (h->order_cap < (long)ncell) {
+        HIP_OK(hipStreamSynchronize(h->stream));
+        if (h->order_dev) (void)hipFree(h->order_dev);
+        HIP_OK(hipMalloc((void **)&h->order_dev, (size_t)ncell * sizeof(int)));
+        h->order_cap = (long)ncell;
+      }
+      std::vector<int> order((size_t)ncell);
+      for (long c0 = 0; c0 < (long)ncell; c0 += chunk_cells) {
+        const long nc = std::min<long>(chunk_cells, (long)ncell - c0);
+        for (long i = 0; i < nc; ++i) order[c0 + i] = (int)i;
+        const double *cost = h->cost_hints.data() + c0;
+        std::stable_sort(order.begin() + c0, order.begin() + c0 + nc, [&](int a, int b) { return cost[a] > cost[b]; });
+      }
+      HIP_OK(hipMemcpy(h->order_dev, order.data(), (size_t)ncell * sizeof(int), hipMemcpyHostToDevice));
+    }
     for (long c0 = 0; c0 < (long)ncell; c0 += chunk_cells) {
       const long nc = std::min<long>(chunk_cells, (long)ncell - c0);
       const double *cells_c = (const double *)dc.d + (size_t)c0 * RACGPU_NPAR;
@@ -658,7 +731,7 @@ int racgpu_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell,
                          (double *)dy.d + (size_t)c0 * nS, dt.d ? (double *)dt.d + c0 : nullptr, dq.d ? (int *)dq.d + c0 : nullptr,
                          ds.d ? (long long *)ds.d + (size_t)c0 * RACGPU_NSTAT : nullptr,
                          drec.d ? (double *)drec.d + (size_t)c0 * P.n_record * (nS + 1) : nullptr,
-                         dto.d ? (double *)dto.d + (size_t)c0 * P.n_record : nullptr);
+                         dto.d ? (double *)dto.d + (size_t)c0 * P.n_record : nullptr, hinted ? h->order_dev + c0 : nullptr);
       HIP_OK(hipGetLastError());
     }
     HIP_OK(hipEventRecord(h->ev1, h->stream));

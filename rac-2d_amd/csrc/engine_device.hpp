@@ -275,6 +275,9 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
   wave_sync();
 }
 
+#ifndef RG_TS_DEPTH
+#define RG_TS_DEPTH 8
+#endif
 RG_DEV void lds_order() {
   // Hot-loop variant of lds_sync: only pins the instruction order.  The LDS executes one wave's operations in
   // issue order, and every access it separates goes through a run-time index into the same array, so the
@@ -293,9 +296,8 @@ RG_DEV void lds_sync() {
 
 // Left-looking column LDU of the permuted P: P' = L * D * U, L unit lower, U unit upper, D^-1 stored.
 // w is the wave's LDS work column.  Returns false on an exactly zero pivot (DPRJS IERPJ = 1).
-// For column j the list of pivots k (rows of U(:,j)) and the extents of their L columns are fetched 64 at a
-// time into registers, and the L column of pivot t+1 is already in flight while pivot t updates w, so the
-// dependent chain per pivot is LDS-only (read w[k], fma, write w[i]).
+// Everything a column needs first (its extents, its P entries, its pivot descriptors, the row lists of its U and
+// L parts) is fetched while the previous column is being worked on.
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
                    double *__restrict__ Dinv, double *w, double *w2, double *dl, int lane, long long *cyc = nullptr) {
   // w: LDS work column (w2: spare LDS vector, unused);
@@ -306,80 +308,107 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   const int n = N.nS, ns = N.ns;
   const RG_GLOBAL uint16_t *Lrow = gptr(N.Lrow), *Urow = gptr(N.Urow), *Prow = gptr(N.Prow);
   const RG_GLOBAL unsigned long long *Udesc = gptr(N.Udesc);
-  const RG_GLOBAL int *Lcolptr = gptr(N.Lcolptr), *Lcolend = gptr(N.Lcolend), *Ucolptr = gptr(N.Ucolptr), *Ucolend = gptr(N.Ucolend),
-                      *Pcolptr = gptr(N.Pcolptr);
+  const RG_GLOBAL int *Lcolptr = gptr(N.Lcolptr), *Ucolend = gptr(N.Ucolend);
+  const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column
+  auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; return r; };
   (void)w2;
   for (int i = lane; i < n; i += 64) w[i] = 0.0; // the work column is kept all-zero between columns
   lds_sync();
   // start of the L column of every pivot of the dense trailing block, two per lane (constant over the LU)
   const int cpA = (ns + lane < n) ? Lcolptr[ns + lane] : 0, cpB = (ns + 64 + lane < n) ? Lcolptr[ns + 64 + lane] : 0;
   const int rowA = ns + lane, rowB = ns + 64 + lane;
+
+  // one-column-ahead prefetch: extents (scalar), first 64 pivot descriptors, first 64 P entries, first 64 rows of
+  // the U and L parts.  All tables and value slices are padded by 64 entries, so these loads are unconditional.
+  LuCol nxc = load_col(0), cur = nxc;
+  unsigned long long nx_dq; double nx_pv; uint16_t nx_pr, nx_fu, nx_fl, cu_fu = 0, cu_fl = 0;
+  auto prefetch_col = [&]() {
+    nx_dq = Udesc[nxc.d0 + lane]; nx_pv = Pv[nxc.p0 + lane]; nx_pr = Prow[nxc.p0 + lane];
+    nx_fu = Urow[nxc.u0 + lane]; nx_fl = Lrow[nxc.lc0 + lane];
+  };
+  prefetch_col();
   if (cyc) tq = (long long)__builtin_readcyclecounter();
 
   // ---- column j, part 1: scatter P(:,j) into the work column and apply the pivots k < ns through LDS -------------
-  // The pivots of a column and the extents of their L columns come as packed descriptors (k | len<<16 | a0<<32),
-  // fetched 64 at a time; L columns are software-pipelined two pivots ahead with three named register sets (a
-  // register-to-register rotation would have to wait for the loads it moves).  Loads are unconditional: tables and
-  // value slices are padded by 64 entries.  Column bases are wave-uniform, so a load costs no per-lane address math.
+  // Pivot k of column j does w[i] -= L(i,k) * w[k] over the rows i of L(:,k).  The pivots come as packed
+  // descriptors (k | len<<16 | newlevel<<30 | start<<32), 64 at a time, one per lane, sorted so that pivots which
+  // do not feed each other (same level within the column, see build_symbolic) are adjacent: when a level opens,
+  // ONE LDS read fetches w[k] for every lane's pivot, and the pivots of that level take their multiplier from the
+  // owning lane (v_readlane) - no LDS round trip per pivot.  The updates are LDS atomics (ds_add_f64, no return),
+  // so the wave never waits for them either; the LDS executes one wave's operations in issue order, which is what
+  // makes the next level's read see them.  L columns are loaded kLuDepth-1 pivots ahead into register sets
+  // with static indices (the loop is unrolled by the depth).
   auto rect_phase = [&](int j, double *wv) {
-    const int u0 = Ucolptr[j], u1 = Ucolend[j];
-    for (int q = Pcolptr[j] + lane; q < Pcolptr[j + 1]; q += 64) wv[Prow[q]] = Pv[q];
+    cur = nxc; cu_fu = nx_fu; cu_fl = nx_fl;
+    const unsigned long long dq0 = nx_dq;
+    const double pv = nx_pv; const int pr = nx_pr;
+    nxc = load_col(j + 1);
+    prefetch_col();
+    if (lane < cur.p1 - cur.p0) wv[pr] = pv;
+    for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[Prow[q]] = Pv[q]; // rare: > 64 entries
     lds_sync();
     RG_TICK(c_scatter)
-    const int ur = (j > ns) ? u1 - (j - ns) : u1; // pivots ns..j-1 are applied in registers (dense phase)
-    for (int base = u0; base < ur; base += 64) {
-      const int nk = min(64, ur - base);
-      const unsigned long long dq = Udesc[base + lane];
+    constexpr int D = kLuDepth;
+    constexpr int CH = 64 / D * D; // descriptors per fetch: one per lane, a multiple of D
+    for (int base = cur.d0; base < cur.d1; base += CH) {
+      const int nk = min(CH, cur.d1 - base); // a multiple of D (the slices are padded with null descriptors)
+      const unsigned long long dq = (base == cur.d0) ? dq0 : Udesc[base + lane];
       const int dlo = (int)(dq & 0xffffffffull), dhi = (int)(dq >> 32);
+      const int myk = dlo & 0xffff;
+      const unsigned long long opens = __ballot((((dlo >> 30) & 1) != 0 || lane == 0) && lane < nk);
+      double tvv = 0.0;
+      int a[D], z[D];
+      uint16_t i[D];
+      double l[D];
 #define RG_LU_ISSUE(S, tt)                                                                                        \
   {                                                                                                               \
     const int tq_ = min((tt), nk - 1);                                                                             \
-    const int lo_ = __builtin_amdgcn_readlane(dlo, tq_);                                                           \
-    a##S = __builtin_amdgcn_readlane(dhi, tq_);                                                                    \
-    k##S = lo_ & 0xffff; z##S = lo_ >> 16; /* z = column length */                                                 \
-    const RG_GLOBAL uint16_t *rp_ = Lrow + a##S;                                                                   \
-    const double *vp_ = Lv + a##S;                                                                                 \
-    i##S = rp_[lane]; l##S = vp_[lane];                                                                            \
+    a[S] = __builtin_amdgcn_readlane(dhi, tq_);                                                                    \
+    z[S] = (__builtin_amdgcn_readlane(dlo, tq_) >> 16) & 0x3fff; /* rows in this piece of the L column (<= 64) */  \
+    i[S] = (Lrow + a[S])[lane]; l[S] = (Lv + a[S])[lane];                                                          \
   }
-#define RG_LU_APPLY(S)                                                                                            \
-  {                                                                                                               \
-    const double tv = wv[k##S]; /* = d_k * u_kj, final */                                                          \
-    if (lane < z##S) wv[i##S] -= l##S * tv;                                                                        \
-    for (int q = 64 + lane; q < z##S; q += 64) { const int i = Lrow[a##S + q]; wv[i] -= Lv[a##S + q] * tv; } /* rare: > 64 rows */ \
-    lds_order();                                                                                                   \
-  }
-      int k0, a0, z0, k1, a1, z1, k2, a2, z2;
-      uint16_t i0, i1, i2;
-      double l0, l1, l2;
-      RG_LU_ISSUE(0, 0)
-      RG_LU_ISSUE(1, 1)
-      for (int t = 0; t < nk; t += 3) {
-        RG_LU_ISSUE(2, t + 2)
-        RG_LU_APPLY(0)
-        if (t + 1 < nk) {
-          RG_LU_ISSUE(0, t + 3)
-          RG_LU_APPLY(1)
-          if (t + 2 < nk) {
-            RG_LU_ISSUE(1, t + 4)
-            RG_LU_APPLY(2)
+#pragma unroll
+      for (int s = 0; s < D - 1; ++s) RG_LU_ISSUE(s, s)
+      for (int t = 0; t < nk; t += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          RG_LU_ISSUE((s + D - 1) % D, t + s + D - 1)
+          const int tt = t + s;
+          if ((opens >> tt) & 1ull) { // w[k] of this level's pivots is final now
+            lds_order();
+            tvv = wv[myk];
+            asm volatile("" : "+v"(tvv)); // take the LDS wait here, so that pivots which do not open a level never wait on LDS
           }
+          union { double d; int w[2]; } src, tv;
+          src.d = tvv;
+          tv.w[0] = __builtin_amdgcn_readlane(src.w[0], tt);
+          tv.w[1] = __builtin_amdgcn_readlane(src.w[1], tt);
+          if (lane < z[s]) atomicAdd(&wv[i[s]], -(l[s] * tv.d));
+          lds_order();
         }
       }
 #undef RG_LU_ISSUE
-#undef RG_LU_APPLY
     }
     RG_TICK(c_rect)
   };
 
+  // U part of the current column with rows < uend_rect: final after the LDS pivots; scaled and stored
+  auto store_u = [&](double *wv, int uend) {
+    int q = cur.u0 + lane;
+    if (q < uend) { const int k = cu_fu; Uv[q] = wv[k] * dl[k]; wv[k] = 0.0; }
+    for (q += 64; q < uend; q += 64) { const int k = Urow[q]; Uv[q] = wv[k] * dl[k]; wv[k] = 0.0; }
+  };
+
   // ---- column j, last part: pivot, scaled U and L columns to HBM, work column back to zero ------------------------
   auto finish = [&](int j, double *wv) {
-    const int u0 = Ucolptr[j], u1 = Ucolend[j], lc0 = Lcolptr[j], lc1 = Lcolend[j];
     const double d = wv[j];
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
     if (lane == 0) { Dinv[j] = dinv; dl[j] = dinv; wv[j] = 0.0; }
-    for (int q = u0 + lane; q < u1; q += 64) { const int k = Urow[q]; Uv[q] = wv[k] * dl[k]; wv[k] = 0.0; }
-    for (int q = lc0 + lane; q < lc1; q += 64) { const int i = Lrow[q]; Lv[q] = wv[i] * dinv; wv[i] = 0.0; }
+    store_u(wv, cur.u1);
+    int q = cur.lc0 + lane;
+    if (q < cur.lc1) { const int i = cu_fl; Lv[q] = wv[i] * dinv; wv[i] = 0.0; }
+    for (q += 64; q < cur.lc1; q += 64) { const int i = Lrow[q]; Lv[q] = wv[i] * dinv; wv[i] = 0.0; }
     wave_sync(); // L, U, Dinv of this column are read back from HBM by later columns
     RG_TICK(c_fin)
   };
@@ -411,8 +440,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
       if (c < ng) {
         const int jc = j + c;
         rect_phase(jc, w);
-        const int u0 = Ucolptr[jc], ur = Ucolend[jc] - (jc - ns);
-        for (int q = u0 + lane; q < ur; q += 64) { const int k = Urow[q]; Uv[q] = w[k] * dl[k]; w[k] = 0.0; }
+        store_u(w, cur.ur);
         if (rowA < n) { wA[c] = w[rowA]; w[rowA] = 0.0; }
         if (rowB < n) { wB[c] = w[rowB]; w[rowB] = 0.0; }
         lds_sync();
@@ -487,38 +515,31 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 // One triangular sweep: entries stream in level order, 64 per step; every entry does x[row] -= v * x[col].
 // Within a level the columns are independent; entries of different columns may hit the same row, hence the
 // LDS atomic.  The next 64 entries are in flight while the current ones are applied.
+template <int D>
 RG_DEV void dev_tri_sweep(const RG_GLOBAL uint32_t *__restrict__ rc, const double *__restrict__ val, int nchunk, double *w, int lane) {
   if (nchunk <= 0) return;
-  // three named register sets, two chunks ahead (same scheme as the LU pivots); the schedule is padded by four
-  // chunks and the value slices by 256 entries so every prefetch is unconditional
-#define RG_TS_LOAD(S, cc) { r##S = rc[(size_t)(cc) * 64 + lane]; v##S = val[(size_t)(cc) * 64 + lane]; }
-#define RG_TS_APPLY(S)                                                                                            \
-  {                                                                                                               \
-    const int row = (int)(r##S & 1023u), col = (int)((r##S >> 10) & 1023u), lev = (int)(r##S >> 20);               \
-    const int lfirst = __builtin_amdgcn_readfirstlane(lev), llast = __builtin_amdgcn_readlane(lev, 63);            \
-    for (int l = lfirst; l <= llast; ++l) {                                                                        \
-      if (lev == l && row != col) atomicAdd(&w[row], -(v##S * w[col]));                                            \
-      lds_order();                                                                                                 \
-    }                                                                                                              \
-  }
-  uint32_t r0, r1, r2;
-  double v0, v1, v2;
-  RG_TS_LOAD(0, 0)
-  RG_TS_LOAD(1, 1)
-  for (int c = 0; c < nchunk; c += 3) {
-    RG_TS_LOAD(2, c + 2)
-    RG_TS_APPLY(0)
-    if (c + 1 < nchunk) {
-      RG_TS_LOAD(0, c + 3)
-      RG_TS_APPLY(1)
-      if (c + 2 < nchunk) {
-        RG_TS_LOAD(1, c + 4)
-        RG_TS_APPLY(2)
+  // D register sets with static indices (the loop is unrolled by D), D-1 chunks in flight: HBM latency is ~900
+  // cycles and a chunk applies in ~150, so the stream has to run many chunks ahead.  The schedule and the value
+  // slices are padded (D chunks) so every prefetch is unconditional.
+  uint32_t r[D];
+  double v[D];
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) { r[s] = rc[(size_t)s * 64 + lane]; v[s] = val[(size_t)s * 64 + lane]; }
+  for (int c = 0; c < nchunk; c += D) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      if (c + s < nchunk) {
+        const int sl = (s + D - 1) % D; // the set applied one sub-step ago is free again
+        r[sl] = rc[(size_t)(c + s + D - 1) * 64 + lane]; v[sl] = val[(size_t)(c + s + D - 1) * 64 + lane];
+        const int row = (int)(r[s] & 1023u), col = (int)((r[s] >> 10) & 1023u), lev = (int)(r[s] >> 20);
+        const int lfirst = __builtin_amdgcn_readfirstlane(lev), llast = __builtin_amdgcn_readlane(lev, 63);
+        for (int l = lfirst; l <= llast; ++l) {
+          if (lev == l && row != col) atomicAdd(&w[row], -(v[s] * w[col]));
+          lds_order();
+        }
       }
     }
   }
-#undef RG_TS_LOAD
-#undef RG_TS_APPLY
 }
 
 // x <- P^-1 x with the factors above; x (species order) and w are LDS vectors (DSOLSS / CDRV path 4)
@@ -528,10 +549,10 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
   lds_sync();
   for (int i = lane; i < n; i += 64) w[i] = x[gptr(N.perm)[i]];
   lds_sync();
-  dev_tri_sweep(gptr(N.Lrc), Lv, N.nchunkL, w, lane);
+  dev_tri_sweep<RG_TS_DEPTH>(gptr(N.Lrc), Lv, N.nchunkL, w, lane);
   for (int i = lane; i < n; i += 64) w[i] = w[i] * Dinv[i];
   lds_sync();
-  dev_tri_sweep(gptr(N.Urc), Uv, N.nchunkU, w, lane);
+  dev_tri_sweep<RG_TS_DEPTH>(gptr(N.Urc), Uv, N.nchunkU, w, lane);
   for (int i = lane; i < n; i += 64) x[gptr(N.perm)[i]] = w[i];
   lds_sync();
 }

@@ -436,7 +436,9 @@ struct CellResult { double t_final; int quality, nerr, nrec_real; long long nst,
 
 RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const CellCtx &c, double t_max, int n_record,
                                  double *__restrict__ record, double *__restrict__ touts, double *trace) {
-  Lsodes s{};
+  __shared__ Lsodes s_lds;
+  Lsodes &s = s_lds;
+  s = Lsodes{};
   s.trace = trace; s.trace_cap = P.debug_max_calls;
   s.tcrit = t_max; s.hmxi = (t_max > 0.0) ? 1.0 / t_max : 0.0; s.mxstep = P.mxstep > 0 ? P.mxstep : 500;
   CellResult R{};

@@ -375,6 +375,30 @@ void build_symbolic(HostNetwork &net) {
     for (int i = 0; i < j; ++i) if (bit(rows, i, j)) Uc[j].push_back(i);
     for (int i = j + 1; i < n; ++i) if (bit(rows, i, j)) Lc[j].push_back(i);
   }
+  // Within column j of U the pivots k < ns are applied through the LDS work column.  Pivot k needs the final value
+  // of row k, i.e. every earlier pivot k' of the same column with L(k,k') != 0 must have been applied: that gives
+  // each pivot a level within its column.  Rows k < ns are stored sorted by (level, k), so the pivots of one level
+  // are adjacent and independent of each other (the kernel fetches all their multipliers with one LDS read);
+  // Ugrp marks the first pivot of every level.  Rows >= ns (dense tail) follow, ascending.
+  std::vector<std::vector<int>> Uflag(n);
+  for (int j = 0; j < n; ++j) {
+    std::vector<int> &r = Uc[j];
+    size_t m = 0;
+    while (m < r.size() && r[m] < S.ns) ++m;
+    std::vector<int> plev(m, 0);
+    for (size_t a = 0; a < m; ++a)
+      for (size_t b = 0; b < a; ++b) if (bit(rows, r[a], r[b])) plev[a] = std::max(plev[a], plev[b] + 1);
+    std::vector<int> idx(m);
+    for (size_t a = 0; a < m; ++a) idx[a] = (int)a;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return plev[a] < plev[b]; });
+    std::vector<int> sorted(r);
+    Uflag[j].assign(r.size(), 0);
+    for (size_t a = 0; a < m; ++a) {
+      sorted[a] = r[idx[a]];
+      Uflag[j][a] = (a == 0 || plev[idx[a]] != plev[idx[a - 1]]) ? 1 : 0;
+    }
+    r = sorted;
+  }
   // dependency levels: forward solve (row i needs every column k < i with L(i,k) != 0), backward likewise
   std::vector<int> llev(n, 0), ulev(n, 0);
   for (int k = 0; k < n; ++k) for (int i : Lc[k]) llev[i] = std::max(llev[i], llev[k] + 1);
@@ -400,6 +424,8 @@ void build_symbolic(HostNetwork &net) {
   lay_out(Lc, llev, false, S.Lcolptr, S.Lcolend, S.Lrow, S.Lcol, S.Llev, S.nlevL);
   lay_out(Uc, ulev, true, S.Ucolptr, S.Ucolend, S.Urow, S.Ucol, S.Ulev, S.nlevU);
   S.nzl = (int)S.Lrow.size(); S.nzu = (int)S.Urow.size();
+  S.Ugrp.assign(S.nzu, 0);
+  for (int j = 0; j < n; ++j) for (size_t a = 0; a < Uflag[j].size(); ++a) S.Ugrp[S.Ucolptr[j] + a] = Uflag[j][a];
   if (n > 1023 || S.nlevL > 4094 || S.nlevU > 4094)
     throw std::runtime_error("network too large for the packed 10/10/12-bit solve schedule (n <= 1023 species)");
   // permuted columns of P

@@ -47,6 +47,7 @@ struct Symbolic { // LU structure of P = I - gamma*J on the species block, cell 
   // Column k occupies [Lcolptr[k], Lcolend[k]) with rows ascending; *lev = dependency level of each column.
   std::vector<int> Lcolptr, Lcolend, Lrow, Lcol, Llev; // per entry: row, column, level of the column
   std::vector<int> Ucolptr, Ucolend, Urow, Ucol, Ulev;
+  std::vector<int> Ugrp; // per U entry: 1 if this pivot (row < ns) opens a new level within its column, see build_symbolic
   int nlevL = 0, nlevU = 0;
   // Columns/rows >= ns form a trailing block that is (made) fully dense in L and U (at most 128 wide): the LU keeps
   // that part of its work column in registers, two rows per lane.

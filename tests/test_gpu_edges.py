@@ -50,6 +50,24 @@ def test_runs_are_bitwise_reproducible(racgpu, setup):
     np.testing.assert_array_equal(a["stats"][:, :8], b["stats"][::-1, :8])
 
 
+def test_cost_hints_change_the_order_not_the_results(racgpu, setup):
+    """racgpu_set_cost_hints: more cells than resident waves would be needed to see the schedule at work; here the
+    check is that any order (including a reversed and a constant one) leaves every output bit unchanged."""
+    net, y0 = setup
+    p = racgpu.default_params(); p.t_max = 1e2
+    cells = racgpu.cells.synth_batch(9, seed=11)
+    base = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells))
+    for cost in (base["stats"][:, 0].astype(float), -np.arange(9.0), np.arange(9.0), np.ones(9)):
+        net.set_cost_hints(cost)
+        out = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells))
+        np.testing.assert_array_equal(out["y"], base["y"])
+        np.testing.assert_array_equal(out["stats"][:, :8], base["stats"][:, :8])
+    net.set_cost_hints(np.ones(4))  # wrong length: ignored
+    out = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells))
+    np.testing.assert_array_equal(out["y"], base["y"])
+    net.set_cost_hints(None)
+
+
 def test_step_budget_stops_a_cell_like_a_premature_finish(racgpu, setup):
     net, y0 = setup
     p = racgpu.default_params(); p.max_steps_per_cell = 100
