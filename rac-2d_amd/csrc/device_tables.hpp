@@ -15,7 +15,7 @@ constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K
 // extents of column j in the U, L and P storage; ur = end of the U entries with rows < ns (the pivots applied through
 // LDS); [d0, d1) = the column's slice of the pivot descriptor stream
 struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, pad[7]; };
-constexpr int kLuDepth = 6; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
+constexpr int kLuDepth = 4; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
 
 struct DevNet {
   int nS, nR, npad;          // npad = nS rounded up to 64
@@ -43,7 +43,7 @@ struct DevNet {
   const uint8_t *jac_isdiag; // [nnzJ]
   // ---- sparse LU of the permuted species block ----
   const uint16_t *perm;      // perm[new] = old
-  const int *Lcolptr, *Lcolend, *Ucolptr, *Ucolend, *Pcolptr; // column k of L is [Lcolptr[k], Lcolend[k]) (level-ordered storage)
+  const int *Lcolptr, *Lcolend, *Ucolptr, *Ucolend, *Udptr, *Pcolptr; // storage layout: see network.hpp, struct Symbolic
   const uint16_t *Lrow, *Urow, *Prow;
   const int *Ppos;            // CSC entry -> position in the permuted-column storage of P
   const uint8_t *Pdiag;       // [nnzJ] in storage order: 1 on the diagonal
@@ -56,6 +56,7 @@ struct DevNet {
   const unsigned long long *Udesc;
   const LuCol *lucol;        // [nS+1] per-column extents for the LU (entry nS repeats nS-1: the column prefetch reads one ahead)
   int nchunkL, nchunkU;
+  int nzl_stream, nzu_stream; // entries of the streamed parts; the trailing columns follow back to back (closed-form starts)
   // type-11 special indices (0-based, -1 none)
   int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;
   const uint8_t *s_tolclass; // 0 generic, 1 one of the ten special species, 2 Grain0/+/-, 3 surface species (applied in that order)

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   long long cyc[4] = {0, 0, 0, 0}, c_lu = 0, c_solve = 0;
   for (int r = 0; r < repeat; ++r) {
     const long long t0 = (long long)__builtin_readcyclecounter();
-    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.acor, v.y, lane, cyc_out ? cyc : nullptr);
+    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.acor, v.y, lane, cyc);
     const long long t1 = (long long)__builtin_readcyclecounter();
     for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
     dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
@@ -295,7 +295,7 @@ void racgpu_network::upload() {
     Lrow.resize(Lrow.size() + 64, 0); Urow.resize(Urow.size() + 64, 0); // the LU prefetch reads up to 64 entries past a column
     Prow.resize(Prow.size() + 64, 0);
     dn.perm = up(perm); dn.Lrow = up(Lrow); dn.Urow = up(Urow); dn.Prow = up(Prow);
-    dn.Lcolptr = up(S.Lcolptr); dn.Lcolend = up(S.Lcolend); dn.Ucolptr = up(S.Ucolptr); dn.Ucolend = up(S.Ucolend);
+    dn.Lcolptr = up(S.Lcolptr); dn.Lcolend = up(S.Lcolend); dn.Ucolptr = up(S.Ucolptr); dn.Ucolend = up(S.Ucolend); dn.Udptr = up(S.Udptr);
     dn.Pcolptr = up(S.Pcolptr); dn.Ppos = up(S.Ppos);
     {
       std::vector<uint8_t> pd(S.Psrc.size(), 0);
@@ -303,11 +303,11 @@ void racgpu_network::upload() {
         for (int q = h.Jcolptr[j]; q < h.Jcolptr[j + 1]; ++q) if (h.Jrow[q] == j) pd[S.Ppos[q]] = 1;
       dn.Pdiag = up(pd);
     }
-    auto pack = [](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, int &nchunk) {
-      std::vector<uint32_t> rc(row.size());
-      for (size_t e = 0; e < row.size(); ++e) rc[e] = (uint32_t)row[e] | ((uint32_t)col[e] << 10) | ((uint32_t)lev[e] << 20);
-      const uint32_t padlev = row.empty() ? 0u : (uint32_t)lev.back();
-      rc.resize((row.size() + 63) / 64 * 64, padlev << 20); // row == col == 0: skipped
+    auto pack = [](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, size_t nstream, int &nchunk) {
+      std::vector<uint32_t> rc(nstream); // the streamed part only: the dense trailing block is solved in registers
+      for (size_t e = 0; e < nstream; ++e) rc[e] = (uint32_t)row[e] | ((uint32_t)col[e] << 10) | ((uint32_t)lev[e] << 20);
+      const uint32_t padlev = nstream == 0 ? 0u : (uint32_t)lev[nstream - 1];
+      rc.resize((nstream + 63) / 64 * 64, padlev << 20); // row == col == 0: skipped
       nchunk = (int)(rc.size() / 64);
       rc.resize(rc.size() + 16 * 64, padlev << 20); // spare chunks: the sweep prefetches unconditionally, up to 15 chunks ahead
       return rc;
@@ -316,7 +316,7 @@ void racgpu_network::upload() {
       std::vector<unsigned long long> ud;
       std::vector<LuCol> lc(nS + 1);
       for (int j = 0; j < nS; ++j) {
-        const int ur = (j > S.ns) ? S.Ucolend[j] - (j - S.ns) : S.Ucolend[j]; // pivots ns..j-1 are applied in registers
+        const int ur = S.Ucolend[j]; // rows < ns only: the pivots ns..j-1 of a trailing column are applied in registers
         LuCol c{};
         c.u0 = S.Ucolptr[j]; c.u1 = S.Ucolend[j]; c.lc0 = S.Lcolptr[j]; c.lc1 = S.Lcolend[j]; c.p0 = S.Pcolptr[j]; c.p1 = S.Pcolptr[j + 1];
         c.ur = ur; c.d0 = (int)ud.size();
@@ -336,8 +336,9 @@ void racgpu_network::upload() {
       lc[nS] = nS > 0 ? lc[nS - 1] : LuCol{};
       dn.lucol = up(lc);
     }
-    dn.Lrc = up(pack(S.Lrow, S.Lcol, S.Llev, dn.nchunkL));
-    dn.Urc = up(pack(S.Urow, S.Ucol, S.Ulev, dn.nchunkU));
+    dn.nzl_stream = S.nzl_stream; dn.nzu_stream = S.nzu_stream;
+    dn.Lrc = up(pack(S.Lrow, S.Lcol, S.Llev, (size_t)S.nzl_stream, dn.nchunkL));
+    dn.Urc = up(pack(S.Urow, S.Ucol, S.Ulev, (size_t)S.nzu_stream, dn.nchunkU));
   }
   dn.i_H = h.idx10[1] - 1; dn.i_E = h.idx10[2] - 1; dn.i_gH = h.i_gH - 1; dn.i_gH2 = h.i_gH2 - 1; dn.i_gH2O = h.i_gH2O - 1;
   dn.i_Grain0 = h.i_Grain0 - 1; dn.i_GrainM = h.i_GrainM - 1; dn.i_GrainP = h.i_GrainP - 1;

@@ -25,6 +25,32 @@ RG_DEV void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Buffer addressing for the hot loops: the base of an array lives in a 4-SGPR resource, the wave-uniform part of
+// the index in a scalar offset and the lane part in ONE VGPR shared by every array of the same element size.
+// Compared with global_load on per-lane 64-bit pointers this removes the per-lane base pointers (two VGPRs per
+// array, hoisted out of every loop and live through the whole kernel) and the 64-bit VALU address arithmetic.
+// Offsets are bytes, unsigned, < 2 GiB from the base.
+#ifdef RG_NOBUF // developer switch: the same offsets through plain global loads/stores
+struct rsrc_t { const char *p; };
+RG_DEV rsrc_t mkbuf(const void *p) { return rsrc_t{(const char *)p}; }
+RG_DEV double bload_f64(rsrc_t r, int voff, int soff) { return *(const double *)(r.p + (unsigned)soff + (unsigned)voff); }
+RG_DEV unsigned long long bload_u64(rsrc_t r, int voff, int soff) { return *(const unsigned long long *)(r.p + (unsigned)soff + (unsigned)voff); }
+RG_DEV uint32_t bload_u32(rsrc_t r, int voff, int soff) { return *(const uint32_t *)(r.p + (unsigned)soff + (unsigned)voff); }
+RG_DEV uint16_t bload_u16(rsrc_t r, int voff, int soff) { return *(const uint16_t *)(r.p + (unsigned)soff + (unsigned)voff); }
+RG_DEV void bstore_f64(rsrc_t r, int voff, int soff, double v) { *(double *)(r.p + (unsigned)soff + (unsigned)voff) = v; }
+#else
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+RG_DEV rsrc_t mkbuf(const void *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000); }
+RG_DEV double bload_f64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+RG_DEV unsigned long long bload_u64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
+RG_DEV uint32_t bload_u32(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+RG_DEV uint16_t bload_u16(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+RG_DEV void bstore_f64(rsrc_t r, int voff, int soff, double v) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
+#endif
 RG_DEV double uniform_d(double v) {
   union { double d; int i[2]; } u; u.d = v;
   u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
@@ -201,12 +227,14 @@ RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double ns
   for (int i = lane; i < N.nS; i += 64) ydot[i] = 0.0;
   wave_sync();
   // one-iteration-ahead software prefetch of the reaction rows and the rate vector (all padded by 64 entries)
-  const RG_GLOBAL uint64_t *W0 = gptr(N.rhs_w0), *W1 = gptr(N.rhs_w1), *W2 = gptr(N.rhs_w2);
-  uint64_t w0 = W0[lane], w1 = W1[lane], w2 = W2[lane];
-  double k = rates[lane];
-  for (int r = lane; r < N.nR; r += 64) {
-    const uint64_t w0n = W0[r + 64], w1n = W1[r + 64], w2n = W2[r + 64];
-    const double kn = rates[r + 64];
+  const rsrc_t bW0 = mkbuf(N.rhs_w0), bW1 = mkbuf(N.rhs_w1), bW2 = mkbuf(N.rhs_w2), bK = mkbuf(rates);
+  const int l8 = lane * 8;
+  uint64_t w0 = bload_u64(bW0, l8, 0), w1 = bload_u64(bW1, l8, 0), w2 = bload_u64(bW2, l8, 0);
+  double k = bload_f64(bK, l8, 0);
+  for (int r0 = 0; r0 < N.nR; r0 += 64) {
+    const int r = r0 + lane, nx = (r0 + 64) * 8;
+    const uint64_t w0n = bload_u64(bW0, l8, nx), w1n = bload_u64(bW1, l8, nx), w2n = bload_u64(bW2, l8, nx);
+    const double kn = bload_f64(bK, l8, nx);
     const int kind = (int)(w0 & 0xff);
     if (kind != K_NONE_) {
       const int nre = (int)((w0 >> 8) & 0xff), a = (int)((w0 >> 16) & 0xffff), b = (int)((w0 >> 32) & 0xffff);
@@ -276,7 +304,7 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
 }
 
 #ifndef RG_TS_DEPTH
-#define RG_TS_DEPTH 8
+#define RG_TS_DEPTH 4
 #endif
 RG_DEV void lds_order() {
   // Hot-loop variant of lds_sync: only pins the instruction order.  The LDS executes one wave's operations in
@@ -306,25 +334,25 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   long long c_scatter = 0, c_rect = 0, c_dense = 0, c_fin = 0, tq = 0;
 #define RG_TICK(acc) if (cyc) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - tq; tq = now_; }
   const int n = N.nS, ns = N.ns;
-  const RG_GLOBAL uint16_t *Lrow = gptr(N.Lrow), *Urow = gptr(N.Urow), *Prow = gptr(N.Prow);
-  const RG_GLOBAL unsigned long long *Udesc = gptr(N.Udesc);
-  const RG_GLOBAL int *Lcolptr = gptr(N.Lcolptr), *Ucolend = gptr(N.Ucolend);
+  const rsrc_t bLrow = mkbuf(N.Lrow), bUrow = mkbuf(N.Urow), bProw = mkbuf(N.Prow), bUdesc = mkbuf(N.Udesc), bP = mkbuf(Pv), bL = mkbuf(Lv),
+               bU = mkbuf(Uv);
+  const int l2 = lane * 2, l8 = lane * 8; // lane part of every byte offset (u16 and 8-byte arrays)
   const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column
   auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; return r; };
   (void)w2;
   for (int i = lane; i < n; i += 64) w[i] = 0.0; // the work column is kept all-zero between columns
   lds_sync();
-  // start of the L column of every pivot of the dense trailing block, two per lane (constant over the LU)
-  const int cpA = (ns + lane < n) ? Lcolptr[ns + lane] : 0, cpB = (ns + 64 + lane < n) ? Lcolptr[ns + 64 + lane] : 0;
-  const int rowA = ns + lane, rowB = ns + 64 + lane;
+  // the trailing columns are stored back to back in index order, so their starts have closed forms (scalar ALU)
+  const int nzls = N.nzl_stream, nzus = N.nzu_stream, nt = n - ns;
+  const int rowA = ns + lane, rowB = ns + 64 + lane, rA8 = rowA * 8, rB8 = rowB * 8;
 
   // one-column-ahead prefetch: extents (scalar), first 64 pivot descriptors, first 64 P entries, first 64 rows of
   // the U and L parts.  All tables and value slices are padded by 64 entries, so these loads are unconditional.
   LuCol nxc = load_col(0), cur = nxc;
   unsigned long long nx_dq; double nx_pv; uint16_t nx_pr, nx_fu, nx_fl, cu_fu = 0, cu_fl = 0;
   auto prefetch_col = [&]() {
-    nx_dq = Udesc[nxc.d0 + lane]; nx_pv = Pv[nxc.p0 + lane]; nx_pr = Prow[nxc.p0 + lane];
-    nx_fu = Urow[nxc.u0 + lane]; nx_fl = Lrow[nxc.lc0 + lane];
+    nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = bload_f64(bP, l8, nxc.p0 * 8); nx_pr = bload_u16(bProw, l2, nxc.p0 * 2);
+    nx_fu = bload_u16(bUrow, l2, nxc.u0 * 2); nx_fl = bload_u16(bLrow, l2, nxc.lc0 * 2);
   };
   prefetch_col();
   if (cyc) tq = (long long)__builtin_readcyclecounter();
@@ -345,14 +373,14 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     nxc = load_col(j + 1);
     prefetch_col();
     if (lane < cur.p1 - cur.p0) wv[pr] = pv;
-    for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[Prow[q]] = Pv[q]; // rare: > 64 entries
+    for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[bload_u16(bProw, q * 2, 0)] = bload_f64(bP, q * 8, 0); // rare: > 64 entries
     lds_sync();
     RG_TICK(c_scatter)
     constexpr int D = kLuDepth;
     constexpr int CH = 64 / D * D; // descriptors per fetch: one per lane, a multiple of D
     for (int base = cur.d0; base < cur.d1; base += CH) {
       const int nk = min(CH, cur.d1 - base); // a multiple of D (the slices are padded with null descriptors)
-      const unsigned long long dq = (base == cur.d0) ? dq0 : Udesc[base + lane];
+      const unsigned long long dq = (base == cur.d0) ? dq0 : bload_u64(bUdesc, l8, base * 8);
       const int dlo = (int)(dq & 0xffffffffull), dhi = (int)(dq >> 32);
       const int myk = dlo & 0xffff;
       const unsigned long long opens = __ballot((((dlo >> 30) & 1) != 0 || lane == 0) && lane < nk);
@@ -365,7 +393,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     const int tq_ = min((tt), nk - 1);                                                                             \
     a[S] = __builtin_amdgcn_readlane(dhi, tq_);                                                                    \
     z[S] = (__builtin_amdgcn_readlane(dlo, tq_) >> 16) & 0x3fff; /* rows in this piece of the L column (<= 64) */  \
-    i[S] = (Lrow + a[S])[lane]; l[S] = (Lv + a[S])[lane];                                                          \
+    i[S] = bload_u16(bLrow, l2, a[S] * 2); l[S] = bload_f64(bL, l8, a[S] * 8);                                     \
   }
 #pragma unroll
       for (int s = 0; s < D - 1; ++s) RG_LU_ISSUE(s, s)
@@ -395,8 +423,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   // U part of the current column with rows < uend_rect: final after the LDS pivots; scaled and stored
   auto store_u = [&](double *wv, int uend) {
     int q = cur.u0 + lane;
-    if (q < uend) { const int k = cu_fu; Uv[q] = wv[k] * dl[k]; wv[k] = 0.0; }
-    for (q += 64; q < uend; q += 64) { const int k = Urow[q]; Uv[q] = wv[k] * dl[k]; wv[k] = 0.0; }
+    if (q < uend) { const int k = cu_fu; bstore_f64(bU, l8, cur.u0 * 8, wv[k] * dl[k]); wv[k] = 0.0; }
+    for (q += 64; q < uend; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); bstore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
   };
 
   // ---- column j, last part: pivot, scaled U and L columns to HBM, work column back to zero ------------------------
@@ -407,8 +435,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     if (lane == 0) { Dinv[j] = dinv; dl[j] = dinv; wv[j] = 0.0; }
     store_u(wv, cur.u1);
     int q = cur.lc0 + lane;
-    if (q < cur.lc1) { const int i = cu_fl; Lv[q] = wv[i] * dinv; wv[i] = 0.0; }
-    for (q += 64; q < cur.lc1; q += 64) { const int i = Lrow[q]; Lv[q] = wv[i] * dinv; wv[i] = 0.0; }
+    if (q < cur.lc1) { const int i = cu_fl; bstore_f64(bL, l8, cur.lc0 * 8, wv[i] * dinv); wv[i] = 0.0; }
+    for (q += 64; q < cur.lc1; q += 64) { const int i = bload_u16(bLrow, q * 2, 0); bstore_f64(bL, q * 8, 0, wv[i] * dinv); wv[i] = 0.0; }
     wave_sync(); // L, U, Dinv of this column are read back from HBM by later columns
     RG_TICK(c_fin)
   };
@@ -450,10 +478,10 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 #define RG_DENSE_LOAD(LA, LB, kb_)                                                                               \
   _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
     const int k = min((kb_) + u, max(j - 1, ns)), kk = k - ns;                                                    \
-    const int cp = (kk < 64) ? __builtin_amdgcn_readlane(cpA, kk) : __builtin_amdgcn_readlane(cpB, kk - 64);      \
-    const double *col = Lv + cp - k - 1; /* col[row] = L(row, k) */                                               \
-    LA[u] = (rowA > k && rowA < n) ? col[rowA] : 0.0;                                                             \
-    LB[u] = (rowB > k && rowB < n) ? col[rowB] : 0.0;                                                             \
+    const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - k - 1) * 8; /* byte offset of L(0, k): L(row, k) sits row*8 further */ \
+    const double va = bload_f64(bL, rA8, cb), vb = bload_f64(bL, rB8, cb); /* unconditional: rows outside the column read neighbouring entries */ \
+    LA[u] = (rowA > k && rowA < n) ? va : 0.0;                                                                    \
+    LB[u] = (rowB > k && rowB < n) ? vb : 0.0;                                                                    \
   }
 #define RG_DENSE_APPLY(LA, LB, kb_)                                                                              \
   _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
@@ -496,12 +524,12 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
           }
         }
         lds_sync(); // dl[jc] is read below by the lanes of later columns
-        double *Ut = Uv + (Ucolend[jc] - kk) - ns; // Ut[row] = U(row, jc) for ns <= row < jc
-        double *Lt = Lv + Lcolptr[jc] - jc - 1;    // Lt[row] = L(row, jc) for row > jc
-        if (rowA < jc) Ut[rowA] = wA[c] * dl[rowA];
-        else if (rowA > jc && rowA < n) Lt[rowA] = lA;
-        if (rowB < jc) Ut[rowB] = wB[c] * dl[rowB];
-        else if (rowB > jc && rowB < n) Lt[rowB] = lB;
+        const int ub = ((nzus + kk * (kk - 1) / 2) - ns) * 8;                    // byte offset of U(0, jc): rows ns <= row < jc are stored
+        const int lb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - jc - 1) * 8; // byte offset of L(0, jc): rows > jc are stored
+        if (rowA < jc) bstore_f64(bU, rA8, ub, wA[c] * dl[rowA]);
+        else if (rowA > jc && rowA < n) bstore_f64(bL, rA8, lb, lA);
+        if (rowB < jc) bstore_f64(bU, rB8, ub, wB[c] * dl[rowB]);
+        else if (rowB > jc && rowB < n) bstore_f64(bL, rB8, lb, lB);
       }
     }
     wave_sync(); // L, U, Dinv of these columns are read back from HBM by later columns
@@ -516,21 +544,23 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 // Within a level the columns are independent; entries of different columns may hit the same row, hence the
 // LDS atomic.  The next 64 entries are in flight while the current ones are applied.
 template <int D>
-RG_DEV void dev_tri_sweep(const RG_GLOBAL uint32_t *__restrict__ rc, const double *__restrict__ val, int nchunk, double *w, int lane) {
+RG_DEV void dev_tri_sweep(const uint32_t *__restrict__ rc, const double *__restrict__ val, int nchunk, double *w, int lane) {
   if (nchunk <= 0) return;
   // D register sets with static indices (the loop is unrolled by D), D-1 chunks in flight: HBM latency is ~900
   // cycles and a chunk applies in ~150, so the stream has to run many chunks ahead.  The schedule and the value
   // slices are padded (D chunks) so every prefetch is unconditional.
   uint32_t r[D];
   double v[D];
+  const rsrc_t brc = mkbuf(rc), bval = mkbuf(val);
+  const int l4 = lane * 4, l8 = lane * 8;
 #pragma unroll
-  for (int s = 0; s < D - 1; ++s) { r[s] = rc[(size_t)s * 64 + lane]; v[s] = val[(size_t)s * 64 + lane]; }
+  for (int s = 0; s < D - 1; ++s) { r[s] = bload_u32(brc, l4, s * 256); v[s] = bload_f64(bval, l8, s * 512); }
   for (int c = 0; c < nchunk; c += D) {
 #pragma unroll
     for (int s = 0; s < D; ++s) {
       if (c + s < nchunk) {
         const int sl = (s + D - 1) % D; // the set applied one sub-step ago is free again
-        r[sl] = rc[(size_t)(c + s + D - 1) * 64 + lane]; v[sl] = val[(size_t)(c + s + D - 1) * 64 + lane];
+        r[sl] = bload_u32(brc, l4, (c + s + D - 1) * 256); v[sl] = bload_f64(bval, l8, (c + s + D - 1) * 512);
         const int row = (int)(r[s] & 1023u), col = (int)((r[s] >> 10) & 1023u), lev = (int)(r[s] >> 20);
         const int lfirst = __builtin_amdgcn_readfirstlane(lev), llast = __builtin_amdgcn_readlane(lev, 63);
         for (int l = lfirst; l <= llast; ++l) {
@@ -542,17 +572,91 @@ RG_DEV void dev_tri_sweep(const RG_GLOBAL uint32_t *__restrict__ rc, const doubl
   }
 }
 
-// x <- P^-1 x with the factors above; x (species order) and w are LDS vectors (DSOLSS / CDRV path 4)
+// x <- P^-1 x with the factors above; x (species order) and w are LDS vectors (DSOLSS / CDRV path 4).
+// The streamed parts of L and U go through dev_tri_sweep; the dense trailing block (rows/columns >= ns) is solved
+// in registers, two rows per lane: column k takes its x_k from the owning lane (v_readlane) and its L (or U) column
+// with one contiguous load per half, RG_DS_DEPTH columns in flight.  Loads are unconditional (row index clamped into
+// the column), the unused lanes are switched off by a select, so the loops are free of branches.
+#ifndef RG_DS_DEPTH
+#define RG_DS_DEPTH 4
+#endif
 RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const double *__restrict__ Uv, const double *__restrict__ Dinv,
                       double *x, double *w, int lane) {
-  const int n = N.nS;
+  const int n = N.nS, ns = N.ns, nt = n - ns;
   lds_sync();
   for (int i = lane; i < n; i += 64) w[i] = x[gptr(N.perm)[i]];
   lds_sync();
-  dev_tri_sweep<RG_TS_DEPTH>(gptr(N.Lrc), Lv, N.nchunkL, w, lane);
-  for (int i = lane; i < n; i += 64) w[i] = w[i] * Dinv[i];
+  dev_tri_sweep<RG_TS_DEPTH>(N.Lrc, Lv, N.nchunkL, w, lane); // columns k < ns
   lds_sync();
-  dev_tri_sweep<RG_TS_DEPTH>(gptr(N.Urc), Uv, N.nchunkU, w, lane);
+  const int rowA = ns + lane, rowB = ns + 64 + lane, rA8 = rowA * 8, rB8 = rowB * 8;
+  const bool hasA = rowA < n, hasB = rowB < n;
+  const rsrc_t bL = mkbuf(Lv), bU = mkbuf(Uv);
+  double xA = hasA ? w[rowA] : 0.0, xB = hasB ? w[rowB] : 0.0;
+  auto bcast = [&](int kk) -> double { // x of trailing row ns + kk
+    union { double d; int i[2]; } s, t;
+    s.d = (kk < 64) ? xA : xB;
+    const int src = (kk < 64) ? kk : kk - 64;
+    t.i[0] = __builtin_amdgcn_readlane(s.i[0], src);
+    t.i[1] = __builtin_amdgcn_readlane(s.i[1], src);
+    return t.d;
+  };
+  // the trailing columns are stored back to back in index order, so their starts have closed forms (scalar ALU)
+  const int nzls = N.nzl_stream, nzus = N.nzu_stream;
+  constexpr int D = RG_DS_DEPTH;
+  if (nt > 1) {
+    // forward: columns k = ns .. n-2 of L, rows k+1 .. n-1
+    double la[D], lb[D];
+#define RG_DS_LOAD(S, k_)                                                                                          \
+  {                                                                                                               \
+    const int kc_ = min((k_), n - 2); /* (not "k": the argument may mention the caller's k) */                     \
+    const int kk = kc_ - ns;                                                                                       \
+    const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - kc_ - 1) * 8; /* byte offset of L(0, k); rows k < row < n are stored */ \
+    la[S] = bload_f64(bL, rA8, cb); lb[S] = bload_f64(bL, rB8, cb); /* rows outside the column read neighbouring entries */ \
+  }
+#pragma unroll
+    for (int s = 0; s < D; ++s) RG_DS_LOAD(s, ns + s)
+    for (int k0 = ns; k0 < n - 1; k0 += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const int k = k0 + s; // k > n-2: nothing left below the diagonal, the selects below switch every lane off
+        const double t = bcast(min(k - ns, nt - 1));
+        xA -= ((rowA > k && hasA) ? la[s] : 0.0) * t;
+        xB -= ((rowB > k && hasB) ? lb[s] : 0.0) * t;
+        RG_DS_LOAD(s, k + D)
+      }
+    }
+#undef RG_DS_LOAD
+  }
+  for (int i = lane; i < ns; i += 64) w[i] = w[i] * Dinv[i];
+  if (hasA) xA = xA * Dinv[rowA];
+  if (hasB) xB = xB * Dinv[rowB];
+  if (nt > 1) {
+    // backward: columns k = n-1 .. ns+1 of U, rows ns .. k-1
+    double ua[D], ub[D];
+#define RG_DS_LOAD(S, k_)                                                                                          \
+  {                                                                                                               \
+    const int kk = max((k_), ns + 1) - ns;                                                                         \
+    const int cb = ((nzus + kk * (kk - 1) / 2) - ns) * 8; /* byte offset of U(0, k); rows ns <= row < k are stored */ \
+    ua[S] = bload_f64(bU, rA8, cb); ub[S] = bload_f64(bU, rB8, cb);                                                \
+  }
+#pragma unroll
+    for (int s = 0; s < D; ++s) RG_DS_LOAD(s, n - 1 - s)
+    for (int k0 = n - 1; k0 > ns; k0 -= D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const int k = k0 - s; // k <= ns: no rows of the block above the diagonal, every lane is switched off
+        const double t = bcast(max(k - ns, 0));
+        xA -= ((rowA < k && hasA) ? ua[s] : 0.0) * t;
+        xB -= ((rowB < k && hasB) ? ub[s] : 0.0) * t;
+        RG_DS_LOAD(s, k - D)
+      }
+    }
+#undef RG_DS_LOAD
+  }
+  if (hasA) w[rowA] = xA;
+  if (hasB) w[rowB] = xB;
+  lds_sync();
+  dev_tri_sweep<RG_TS_DEPTH>(N.Urc, Uv, N.nchunkU, w, lane); // rows < ns of every column
   for (int i = lane; i < n; i += 64) x[gptr(N.perm)[i]] = w[i];
   lds_sync();
 }

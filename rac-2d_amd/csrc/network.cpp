@@ -399,33 +399,57 @@ void build_symbolic(HostNetwork &net) {
     }
     r = sorted;
   }
-  // dependency levels: forward solve (row i needs every column k < i with L(i,k) != 0), backward likewise
+  // Storage.  The triangular solves stream the "sparse" part of L and U in dependency-level order (all columns
+  // whose x_k is final at the same depth are adjacent, so a solve is one linear sweep over the value array) and do
+  // the dense trailing block in registers:
+  //   L stream: columns k < ns (their rows may lie anywhere), by forward level; then, outside the stream, the
+  //             columns k >= ns (rows k+1..n-1, contiguous) in index order.
+  //   U stream: for every column its rows < ns; the columns k >= ns come first, at level 0, because the backward
+  //             solve finishes x_k, k >= ns, in registers before the stream starts; then the columns k < ns by
+  //             backward level.  Outside the stream, for k >= ns, the rows ns..k-1 (contiguous) at Udptr[k].
   std::vector<int> llev(n, 0), ulev(n, 0);
   for (int k = 0; k < n; ++k) for (int i : Lc[k]) llev[i] = std::max(llev[i], llev[k] + 1);
-  for (int k = n - 1; k >= 0; --k) for (int i : Uc[k]) ulev[i] = std::max(ulev[i], ulev[k] + 1);
-  auto lay_out = [&](const std::vector<std::vector<int>> &cols, const std::vector<int> &lev, bool descending,
-                     std::vector<int> &ptr, std::vector<int> &end, std::vector<int> &row, std::vector<int> &col,
-                     std::vector<int> &elev, int &nlev) {
-    std::vector<int> order(n);
-    for (int k = 0; k < n; ++k) order[k] = k;
+  for (int k = n - 1; k >= 0; --k) {
+    if (k >= S.ns) ulev[k] = 0;
+    for (int i : Uc[k]) if (i < S.ns) ulev[i] = std::max(ulev[i], ulev[k] + 1);
+  }
+  auto level_order = [&](const std::vector<int> &lev, int kend, bool descending) {
+    std::vector<int> order(kend);
+    for (int k = 0; k < kend; ++k) order[k] = k;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
       if (lev[a] != lev[b]) return lev[a] < lev[b];
       return descending ? a > b : a < b;
     });
-    ptr.assign(n, 0); end.assign(n, 0); row.clear(); col.clear(); elev.clear();
-    nlev = 0;
-    for (int k : order) {
-      ptr[k] = (int)row.size();
-      for (int i : cols[k]) { row.push_back(i); col.push_back(k); elev.push_back(lev[k]); }
-      end[k] = (int)row.size();
-      if (!cols[k].empty()) nlev = std::max(nlev, lev[k] + 1);
-    }
+    return order;
   };
-  lay_out(Lc, llev, false, S.Lcolptr, S.Lcolend, S.Lrow, S.Lcol, S.Llev, S.nlevL);
-  lay_out(Uc, ulev, true, S.Ucolptr, S.Ucolend, S.Urow, S.Ucol, S.Ulev, S.nlevU);
+  S.Lcolptr.assign(n, 0); S.Lcolend.assign(n, 0); S.Lrow.clear(); S.Lcol.clear(); S.Llev.clear(); S.nlevL = 0;
+  for (int k : level_order(llev, S.ns, false)) {
+    S.Lcolptr[k] = (int)S.Lrow.size();
+    for (int i : Lc[k]) { S.Lrow.push_back(i); S.Lcol.push_back(k); S.Llev.push_back(llev[k]); }
+    S.Lcolend[k] = (int)S.Lrow.size();
+    if (!Lc[k].empty()) S.nlevL = std::max(S.nlevL, llev[k] + 1);
+  }
+  S.nzl_stream = (int)S.Lrow.size();
+  for (int k = S.ns; k < n; ++k) {
+    S.Lcolptr[k] = (int)S.Lrow.size();
+    for (int i : Lc[k]) { S.Lrow.push_back(i); S.Lcol.push_back(k); S.Llev.push_back(0); }
+    S.Lcolend[k] = (int)S.Lrow.size();
+  }
+  S.Ucolptr.assign(n, 0); S.Ucolend.assign(n, 0); S.Udptr.assign(n, 0); S.Urow.clear(); S.Ucol.clear(); S.Ulev.clear(); S.nlevU = 0;
+  for (int k : level_order(ulev, n, true)) {
+    S.Ucolptr[k] = (int)S.Urow.size();
+    for (int i : Uc[k]) if (i < S.ns) { S.Urow.push_back(i); S.Ucol.push_back(k); S.Ulev.push_back(ulev[k]); }
+    S.Ucolend[k] = (int)S.Urow.size();
+    if (S.Ucolend[k] > S.Ucolptr[k]) S.nlevU = std::max(S.nlevU, ulev[k] + 1);
+  }
+  S.nzu_stream = (int)S.Urow.size();
+  for (int k = S.ns; k < n; ++k) {
+    S.Udptr[k] = (int)S.Urow.size();
+    for (int i = S.ns; i < k; ++i) { S.Urow.push_back(i); S.Ucol.push_back(k); S.Ulev.push_back(0); }
+  }
   S.nzl = (int)S.Lrow.size(); S.nzu = (int)S.Urow.size();
   S.Ugrp.assign(S.nzu, 0);
-  for (int j = 0; j < n; ++j) for (size_t a = 0; a < Uflag[j].size(); ++a) S.Ugrp[S.Ucolptr[j] + a] = Uflag[j][a];
+  for (int j = 0; j < n; ++j) for (int a = 0; a < S.Ucolend[j] - S.Ucolptr[j]; ++a) S.Ugrp[S.Ucolptr[j] + a] = Uflag[j][a];
   if (n > 1023 || S.nlevL > 4094 || S.nlevU > 4094)
     throw std::runtime_error("network too large for the packed 10/10/12-bit solve schedule (n <= 1023 species)");
   // permuted columns of P

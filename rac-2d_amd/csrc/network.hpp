@@ -42,12 +42,13 @@ struct Symbolic { // LU structure of P = I - gamma*J on the species block, cell 
   int n = 0;
   std::vector<int> perm, iperm;          // perm[new] = old, iperm[old] = new (0-based)
   // L (strict lower, unit diagonal) and U (strict upper, unit diagonal after D scaling) are stored by columns of
-  // the permuted matrix.  Columns are laid out in LEVEL order of the triangular solves (all columns whose x_k is
-  // final at the same dependency depth are adjacent), so a solve is one linear sweep over the value array.
-  // Column k occupies [Lcolptr[k], Lcolend[k]) with rows ascending; *lev = dependency level of each column.
-  std::vector<int> Lcolptr, Lcolend, Lrow, Lcol, Llev; // per entry: row, column, level of the column
-  std::vector<int> Ucolptr, Ucolend, Urow, Ucol, Ulev;
+  // the permuted matrix; the layout (a level-ordered "stream" part plus the dense trailing block) is described in
+  // build_symbolic.  Column k of L occupies [Lcolptr[k], Lcolend[k]); the rows < ns of column k of U occupy
+  // [Ucolptr[k], Ucolend[k]) and, for k >= ns, its rows ns..k-1 start at Udptr[k].  Per entry: row, column, level.
+  std::vector<int> Lcolptr, Lcolend, Lrow, Lcol, Llev;
+  std::vector<int> Ucolptr, Ucolend, Udptr, Urow, Ucol, Ulev;
   std::vector<int> Ugrp; // per U entry: 1 if this pivot (row < ns) opens a new level within its column, see build_symbolic
+  int nzl_stream = 0, nzu_stream = 0; // entries of the streamed parts (they come first in the storage)
   int nlevL = 0, nlevU = 0;
   // Columns/rows >= ns form a trailing block that is (made) fully dense in L and U (at most 128 wide): the LU keeps
   // that part of its work column in registers, two rows per lane.
