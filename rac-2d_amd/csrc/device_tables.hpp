@@ -15,6 +15,7 @@ constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K
 // extents of column j in the U, L and P storage; ur = end of the U entries with rows < ns (the pivots applied through
 // LDS); [d0, d1) = the column's slice of the pivot descriptor stream
 struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, pad[7]; };
+constexpr int kJacUnroll = 8; // rows of the Jacobian term stream per unrolled step (the stream is padded to a multiple)
 constexpr int kLuDepth = 4; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
 
 struct DevNet {
@@ -41,6 +42,10 @@ struct DevNet {
   const int *term_ptr;       // [nnzJ+1]
   const uint64_t *terms;     // rxn | sa<<16 | kind<<32 | flags<<40 | sb<<48
   const uint8_t *jac_isdiag; // [nnzJ]
+  // the same gather as one linear stream (built in engine.hip, upload): jac_rows rows of 64 term words
+  const uint64_t *jac_stream, *jac_slot;
+  const uint32_t *jac_rowflag;
+  int jac_rows;
   // ---- sparse LU of the permuted species block ----
   const uint16_t *perm;      // perm[new] = old
   const int *Lcolptr, *Lcolend, *Ucolptr, *Ucolend, *Udptr, *Pcolptr; // storage layout: see network.hpp, struct Symbolic

@@ -287,6 +287,37 @@ void racgpu_network::upload() {
     for (int j = 0; j < nS; ++j)
       for (int q = h.Jcolptr[j]; q < h.Jcolptr[j + 1]; ++q) if (h.Jrow[q] == j) isd[q] = 1;
     dn.jac_isdiag = up(isd);
+    // Term stream for the Jacobian gather: pass p handles the 64 entries order[64p .. 64p+63], one per lane; row i of
+    // the pass holds term i of every lane's entry (null where an entry has fewer terms), so the kernel reads the terms
+    // as one linear, coalesced, prefetchable stream.  rowflag marks the last row of every pass; slot words say where
+    // each lane's sum goes: entry | position in the permuted P storage << 24 | diagonal << 48 | valid << 49.
+    {
+      const int npass = (int)order.size() / 64;
+      std::vector<uint64_t> stream, slot((size_t)(npass + 1) * 64, 0ull);
+      std::vector<uint32_t> rowflag;
+      for (int p = 0; p < npass; ++p) {
+        int niter = 1;
+        for (int l = 0; l < 64; ++l) {
+          const int e = order[(size_t)p * 64 + l];
+          if (e < 0) continue;
+          niter = std::max(niter, h.term_ptr[e + 1] - h.term_ptr[e]);
+          slot[(size_t)p * 64 + l] = (uint64_t)e | ((uint64_t)h.sym.Ppos[e] << 24) | ((uint64_t)(isd[e] ? 1 : 0) << 48) | (1ull << 49);
+        }
+        for (int i = 0; i < niter; ++i) {
+          for (int l = 0; l < 64; ++l) {
+            const int e = order[(size_t)p * 64 + l];
+            const bool has = e >= 0 && i < h.term_ptr[e + 1] - h.term_ptr[e];
+            stream.push_back(has ? tw[h.term_ptr[e] + i] : ~0ull);
+          }
+          rowflag.push_back(i == niter - 1 ? 1u : 0u);
+        }
+      }
+      while (rowflag.size() % kJacUnroll) { rowflag.push_back(0u); stream.insert(stream.end(), 64, ~0ull); }
+      dn.jac_rows = (int)rowflag.size();
+      stream.insert(stream.end(), (size_t)64 * (kJacUnroll + 8), ~0ull); // the kernel prefetches rows past the end
+      rowflag.resize((rowflag.size() + 63) / 64 * 64 + 64, 0u);
+      dn.jac_stream = up(stream); dn.jac_rowflag = up(rowflag); dn.jac_slot = up(slot);
+    }
   }
   {
     const Symbolic &S = h.sym;

@@ -31,17 +31,9 @@ RG_DEV void wave_sync() {
 // Compared with global_load on per-lane 64-bit pointers this removes the per-lane base pointers (two VGPRs per
 // array, hoisted out of every loop and live through the whole kernel) and the 64-bit VALU address arithmetic.
 // Offsets are bytes, unsigned, < 2 GiB from the base.
-#ifdef RG_NOBUF // developer switch: the same offsets through plain global loads/stores
-struct rsrc_t { const char *p; };
-RG_DEV rsrc_t mkbuf(const void *p) { return rsrc_t{(const char *)p}; }
-RG_DEV double bload_f64(rsrc_t r, int voff, int soff) { return *(const double *)(r.p + (unsigned)soff + (unsigned)voff); }
-RG_DEV unsigned long long bload_u64(rsrc_t r, int voff, int soff) { return *(const unsigned long long *)(r.p + (unsigned)soff + (unsigned)voff); }
-RG_DEV uint32_t bload_u32(rsrc_t r, int voff, int soff) { return *(const uint32_t *)(r.p + (unsigned)soff + (unsigned)voff); }
-RG_DEV uint16_t bload_u16(rsrc_t r, int voff, int soff) { return *(const uint16_t *)(r.p + (unsigned)soff + (unsigned)voff); }
-RG_DEV void bstore_f64(rsrc_t r, int voff, int soff, double v) { *(double *)(r.p + (unsigned)soff + (unsigned)voff) = v; }
-#else
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 RG_DEV rsrc_t mkbuf(const void *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000); }
+RG_DEV rsrc_t mkbuf_n(const void *p, int nbytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, nbytes, 0x00020000); } // loads past nbytes return 0
 RG_DEV double bload_f64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
 RG_DEV unsigned long long bload_u64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
 RG_DEV uint32_t bload_u32(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
@@ -50,7 +42,6 @@ RG_DEV void bstore_f64(rsrc_t r, int voff, int soff, double v) {
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
 }
-#endif
 RG_DEV double uniform_d(double v) {
   union { double d; int i[2]; } u; u.d = v;
   u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
@@ -263,10 +254,11 @@ RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double ns
 }
 
 // d(flux)/d(y_col) for one Jacobian term; chem_ode_jac, reference src/disk.f90:4764-4866
-RG_DEV double dev_dflux(uint64_t term, const double *__restrict__ rates, const RG_GLOBAL double *__restrict__ r_C, double nsite, const double *y) {
+// d(flux of one reaction)/d(y of the column species), k = the reaction's rate coefficient (chem_ode_jac, reference
+// src/disk.f90:4746-4900: same forms and sign rules as the RHS)
+RG_DEV double dev_dflux(uint64_t term, double k, const RG_GLOBAL double *__restrict__ r_C, double nsite, const double *y) {
   const int rxn = (int)(term & 0xffff), sa = (int)((term >> 16) & 0xffff), kind = (int)((term >> 32) & 0xff);
   const int flags = (int)((term >> 40) & 0xff), sb = (int)((term >> 48) & 0xffff);
-  const double k = rates[rxn];
   double v;
   if (kind == K_TWO_) {
     const double ya = y[sa], yb = y[sb];
@@ -283,22 +275,50 @@ RG_DEV double dev_dflux(uint64_t term, const double *__restrict__ rates, const R
   return (flags & 1) ? -v : v;
 }
 
-// J(y) gathered entry by entry in the reference's accumulation order, then P = I + con*J
-// (DPRJS label 100-130, reference src/opkda1.f:1754-1767).  con = 1 and add_identity = false gives plain J.
+// P = I - gamma*J (or J itself) on the pattern, entry by entry: every lane owns one entry per pass and adds up its
+// terms in the reference's accumulation order (reaction order).  The terms come as one linear stream of rows of 64
+// words (device_tables.hpp, jac_stream): term words are fetched 7 rows ahead, the rate coefficient each term names
+// is gathered 3 rows ahead, so the only waits left in the loop are the LDS reads of y.
 template <bool PERMUTED>
 RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, double nsite, const double *y, double con,
                         bool add_identity, double *__restrict__ Pv, int lane) {
   // PERMUTED: write each entry at its place in the permuted-column storage the LU reads with unit stride
   wave_sync();
-  for (int s = lane; s < N.jac_slots; s += 64) {
-    const int e = gptr(N.jac_order)[s];
-    if (e < 0) continue;
-    double sum = 0.0;
-    const int t0 = gptr(N.term_ptr)[e], t1 = gptr(N.term_ptr)[e + 1];
-    for (int t = t0; t < t1; ++t) sum += dev_dflux(gptr(N.terms)[t], rates, gptr(N.r_C), nsite, y);
-    double p = sum * con;
-    if (add_identity && gptr(N.jac_isdiag)[e]) p = p + 1.0;
-    Pv[PERMUTED ? gptr(N.Ppos)[e] : e] = p;
+  constexpr int U = kJacUnroll, DT = U - 1, DR = 3;
+  const rsrc_t bT = mkbuf(N.jac_stream), bF = mkbuf(N.jac_rowflag), bS = mkbuf(N.jac_slot), bP = mkbuf(Pv);
+  const rsrc_t bK = mkbuf_n(rates, N.nR * 8); // sized: the rate index of a null term (0xffff) is out of range and reads as 0
+  const RG_GLOBAL double *r_C = gptr(N.r_C);
+  const int l8 = lane * 8, l4 = lane * 4;
+  uint64_t tw[U];
+  double rk[U];
+#pragma unroll
+  for (int s = 0; s < DT; ++s) tw[s] = bload_u64(bT, l8, s * 512);
+#pragma unroll
+  for (int s = 0; s < DR; ++s) rk[s] = bload_f64(bK, (int)(tw[s] & 0xffff) * 8, 0);
+  uint64_t slot = bload_u64(bS, l8, 0), slot_nx = bload_u64(bS, l8, 512);
+  int pass = 0;
+  double sum = 0.0;
+  uint32_t fl = 0;
+  for (int r0 = 0; r0 < N.jac_rows; r0 += U) {
+    if ((r0 & 63) == 0) fl = bload_u32(bF, l4, r0 * 4); // "last row of its pass" flags of the next 64 rows, one per lane
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+      const int r = r0 + s;
+      tw[(s + DT) % U] = bload_u64(bT, l8, (r + DT) * 512);
+      rk[(s + DR) % U] = bload_f64(bK, (int)(tw[(s + DR) % U] & 0xffff) * 8, 0);
+      const uint64_t term = tw[s];
+      if (term != ~0ull) sum += dev_dflux(term, rk[s], r_C, nsite, y);
+      if (__builtin_amdgcn_readlane((int)fl, r & 63)) { // the pass is complete: every lane stores its entry
+        if ((slot >> 49) & 1ull) {
+          double p = sum * con;
+          if (add_identity && ((slot >> 48) & 1ull)) p = p + 1.0;
+          const int dest = PERMUTED ? (int)((slot >> 24) & 0xffffff) : (int)(slot & 0xffffff);
+          bstore_f64(bP, dest * 8, 0, p);
+        }
+        sum = 0.0; ++pass;
+        slot = slot_nx; slot_nx = bload_u64(bS, l8, (pass + 1) * 512);
+      }
+    }
   }
   wave_sync();
 }
