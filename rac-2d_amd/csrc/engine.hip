@@ -263,7 +263,7 @@ void racgpu_network::upload() {
     for (int &v : dl) v -= 1;
     dn.dupli_ptr = up(h.dupli_ptr); dn.dupli_list = up(dl);
   }
-  w0.resize(w0.size() + 128, 0); w1.resize(w1.size() + 128, ~0ull); w2.resize(w2.size() + 128, ~0ull); // prefetch padding (kind 0 = skipped)
+  w0.resize(w0.size() + 448, 0); w1.resize(w1.size() + 448, ~0ull); w2.resize(w2.size() + 448, ~0ull); // padding: the RHS runs to a multiple of 192 rows and prefetches 128 ahead (kind 0, no targets)
   dn.rhs_w0 = up(w0); dn.rhs_w1 = up(w1); dn.rhs_w2 = up(w2);
   // Jacobian gather: entries sorted by decreasing term count so that the 64 lanes of a pass do similar work
   {
@@ -392,7 +392,7 @@ void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   slots = std::max(slots, ws_slots); rate_cells = std::max(rate_cells, ws_rate_cells);
   free_ws();
   auto alloc = [&](size_t count) { void *d = nullptr; HIP_OK(hipMalloc(&d, count * sizeof(double))); ws_allocs.push_back(d); return (double *)d; };
-  ws.rates = alloc((size_t)rate_cells * dn.nR + 128); // per CELL; +128: the RHS prefetch of the last cell reads past nR
+  ws.rates = alloc((size_t)rate_cells * dn.nR + 448); // per CELL; +448: the RHS of the last cell reads past nR
   ws.yh = alloc((size_t)slots * 6 * dn.npad);
   ws.P = alloc((size_t)slots * dn.nnzJ + 64); // spare: the LU's column prefetch reads up to 63 entries past a column
   ws.L = alloc((size_t)slots * std::max(dn.nzl, 1) + 2048); // spare: prefetches of the last slot read past nzl

@@ -217,43 +217,47 @@ RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double ns
                     const double *y, double *ydot, int lane) {
   for (int i = lane; i < N.nS; i += 64) ydot[i] = 0.0;
   wave_sync();
-  // one-iteration-ahead software prefetch of the reaction rows and the rate vector (all padded by 64 entries)
+  // 64 reactions per step, one per lane; the packed rows (w0: kind | n_reac<<8 | a<<16 | b<<32; w1, w2: the up to
+  // seven species the flux is subtracted from / added to) and the rate vector are fetched two steps ahead (all
+  // padded by 192 entries).  a and b are always valid species indices, so both abundances are read up front and
+  // the three common flux forms are selected without branching; only the surface-layer forms (62, 75) branch.
   const rsrc_t bW0 = mkbuf(N.rhs_w0), bW1 = mkbuf(N.rhs_w1), bW2 = mkbuf(N.rhs_w2), bK = mkbuf(rates);
   const int l8 = lane * 8;
-  uint64_t w0 = bload_u64(bW0, l8, 0), w1 = bload_u64(bW1, l8, 0), w2 = bload_u64(bW2, l8, 0);
-  double k = bload_f64(bK, l8, 0);
-  for (int r0 = 0; r0 < N.nR; r0 += 64) {
-    const int r = r0 + lane, nx = (r0 + 64) * 8;
-    const uint64_t w0n = bload_u64(bW0, l8, nx), w1n = bload_u64(bW1, l8, nx), w2n = bload_u64(bW2, l8, nx);
-    const double kn = bload_f64(bK, l8, nx);
-    const int kind = (int)(w0 & 0xff);
-    if (kind != K_NONE_) {
-      const int nre = (int)((w0 >> 8) & 0xff), a = (int)((w0 >> 16) & 0xffff), b = (int)((w0 >> 32) & 0xffff);
-      const double ya = y[a];
-      double f;
-      if (kind == K_TWO_) {
-        const double yb = y[b];
-        f = k * ya * yb;
-        if (ya < 0.0 && yb < 0.0) f = -f;
-      } else if (kind == K_ONE_) f = k * ya;
-      else if (kind == K_SQ_) { f = k * ya * ya; if (ya < 0.0) f = -f; }
-      else { // surface layer forms (62, 75)
-        double t1 = nsite; if (kind == K_SURF75_) t1 = t1 * r_C[r];
+  constexpr int D = 3;
+  uint64_t w0[D], w1[D], w2[D];
+  double kk[D];
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) { w0[s] = bload_u64(bW0, l8, s * 512); w1[s] = bload_u64(bW1, l8, s * 512); w2[s] = bload_u64(bW2, l8, s * 512); kk[s] = bload_f64(bK, l8, s * 512); }
+  for (int r0 = 0; r0 < N.nR; r0 += 64 * D) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      const int rb = r0 + 64 * s; // rows rb >= nR are padding (kind 0, no targets)
+      {
+        const int nx = (rb + 64 * (D - 1)) * 8, sl = (s + D - 1) % D;
+        w0[sl] = bload_u64(bW0, l8, nx); w1[sl] = bload_u64(bW1, l8, nx); w2[sl] = bload_u64(bW2, l8, nx); kk[sl] = bload_f64(bK, l8, nx);
+      }
+      const uint64_t c0 = w0[s], c1 = w1[s], c2 = w2[s];
+      const double k = kk[s];
+      const int kind = (int)(c0 & 0xff), nre = (int)((c0 >> 8) & 0xff), a = (int)((c0 >> 16) & 0xffff), b = (int)((c0 >> 32) & 0xffff);
+      const double ya = y[a], yb = y[b];
+      const double kya = k * ya;
+      double f2 = kya * yb; if (ya < 0.0 && yb < 0.0) f2 = -f2; // two-body (both-negative sign rule)
+      double fq = kya * ya; if (ya < 0.0) fq = -fq;             // A + A
+      double f = (kind == K_TWO_) ? f2 : ((kind == K_SQ_) ? fq : kya);
+      if (kind == K_SURF_ || kind == K_SURF75_) { // surface layer forms (62, 75)
+        double t1 = nsite; if (kind == K_SURF75_) t1 = t1 * r_C[rb + lane];
         if (t1 <= 0.0) f = k;
         else { const double t = ya / t1; f = (t <= 1e-4) ? k * t : k * (1.0 - exp(-t)); }
       }
 #pragma unroll
-      for (int s = 0; s < 7; ++s) {
-        const int t = (int)(((s < 4 ? (w1 >> (16 * s)) : (w2 >> (16 * (s - 4))))) & 0xffff);
-        if (t != 0xffff) atomicAdd(&ydot[t], s < nre ? -f : f);
+      for (int q = 0; q < 7; ++q) {
+        const int t = (int)(((q < 4 ? (c1 >> (16 * q)) : (c2 >> (16 * (q - 4))))) & 0xffff);
+        if (t != 0xffff) atomicAdd(&ydot[t], q < nre ? -f : f);
       }
     }
-    w0 = w0n; w1 = w1n; w2 = w2n; k = kn;
   }
   wave_sync();
 }
-
-// d(flux)/d(y_col) for one Jacobian term; chem_ode_jac, reference src/disk.f90:4764-4866
 // d(flux of one reaction)/d(y of the column species), k = the reaction's rate coefficient (chem_ode_jac, reference
 // src/disk.f90:4746-4900: same forms and sign rules as the RHS)
 RG_DEV double dev_dflux(uint64_t term, double k, const RG_GLOBAL double *__restrict__ r_C, double nsite, const double *y) {
@@ -368,7 +372,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 
   // one-column-ahead prefetch: extents (scalar), first 64 pivot descriptors, first 64 P entries, first 64 rows of
   // the U and L parts.  All tables and value slices are padded by 64 entries, so these loads are unconditional.
-  LuCol nxc = load_col(0), cur = nxc;
+  LuCol nxc = load_col(0), nx2 = load_col(min(1, n)), cur = nxc; // extents are fetched two columns ahead (scalar loads)
   unsigned long long nx_dq; double nx_pv; uint16_t nx_pr, nx_fu, nx_fl, cu_fu = 0, cu_fl = 0;
   auto prefetch_col = [&]() {
     nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = bload_f64(bP, l8, nxc.p0 * 8); nx_pr = bload_u16(bProw, l2, nxc.p0 * 2);
@@ -390,7 +394,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     cur = nxc; cu_fu = nx_fu; cu_fl = nx_fl;
     const unsigned long long dq0 = nx_dq;
     const double pv = nx_pv; const int pr = nx_pr;
-    nxc = load_col(j + 1);
+    nxc = nx2; nx2 = load_col(min(j + 2, n));
     prefetch_col();
     if (lane < cur.p1 - cur.p0) wv[pr] = pv;
     for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[bload_u16(bProw, q * 2, 0)] = bload_f64(bP, q * 8, 0); // rare: > 64 entries
@@ -450,10 +454,10 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   // ---- column j, last part: pivot, scaled U and L columns to HBM, work column back to zero ------------------------
   auto finish = [&](int j, double *wv) {
     const double d = wv[j];
+    store_u(wv, cur.u1); // needs D^-1 of earlier columns only: the division below overlaps with it
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
     if (lane == 0) { Dinv[j] = dinv; dl[j] = dinv; wv[j] = 0.0; }
-    store_u(wv, cur.u1);
     int q = cur.lc0 + lane;
     if (q < cur.lc1) { const int i = cu_fl; bstore_f64(bL, l8, cur.lc0 * 8, wv[i] * dinv); wv[i] = 0.0; }
     for (q += 64; q < cur.lc1; q += 64) { const int i = bload_u16(bLrow, q * 2, 0); bstore_f64(bL, q * 8, 0, wv[i] * dinv); wv[i] = 0.0; }
