@@ -14,6 +14,12 @@ dt_first_step 1e-8, ratio 1.1, steps_reset_solver 50).  Cells shard embarrassing
 own 10 000 cells (weak scaling); the only exchange is ONE RCCL all-gather of the end-state abundances,
 inside the timed region.  Inputs are resident in HBM before the clock starts.
 
+Scheduling: a few cells in 10^4 need 10-20x the median work.  As between two global
+iterations of the disk model, every pass hands the per-cell cycle counts it measured to the next one
+(racgpu_set_cost_hints), which then starts the costliest cells first; the hand-over is inside the timed region.
+The first warm-up pass has no history and runs in queue order: its rate is reported as
+config.queue_order_first_pass.  --no-hints keeps queue order throughout.  Results do not depend on the order.
+
 metric value = (accepted integrator steps summed over all cells and ranks) / (max over ranks of wall time).
 """
 import argparse
@@ -187,6 +193,17 @@ def main():
         abytes = algorithmic_bytes(nS, net.nReactions, net.nnzJ, net.nzl, net.nzu, nst, nfe, nje, nlu, qsum)
         kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = abytes / (kms * 1e-3) / 1e9
+        # HBM bytes per launch.  PMC counters cannot be read from inside this process; the figure is the per-cell-step
+        # traffic of the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same workload
+        # (profiles/r1_pmc_calibration.json, corrected as MI355X_MICROARCH.md prescribes) times this launch's cell-steps.
+        traffic, traffic_src = None, None
+        try:
+            cal = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_calibration.json")))
+            if cal["workload"]["cells_per_gpu"] == ncell and cal["workload"]["network"] == NETWORK:
+                traffic = cal["bytes_per_cell_step_corrected"] * nst
+                traffic_src = "profiles/r1_pmc_calibration.json: %.0f B per cell-step x %d cell-steps" % (cal["bytes_per_cell_step_corrected"], int(nst))
+        except Exception:
+            pass
         out = {
             "metric": "cell-steps/s (whole node)", "value": steps_all / t_all, "unit": "cell-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_all / args.steps,
@@ -201,7 +218,8 @@ def main():
                        "queue_order_first_pass": ({"ms": 1e3 * first_pass_s, "cell_steps_per_s_rank0": float(stats[:, 0].sum()) / first_pass_s}
                                                   if (first_pass_s and hinted) else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_solve", "kernel_ms": kms, "algorithmic_bytes_per_launch": abytes,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_solve", "kernel_ms": kms,
+                         "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_cell_step": abytes / max(nst, 1.0)},
             "cell_steps_per_pass_rank0": nst, "mean_steps_per_cell": nst / ncell,
             "nfe_per_step": nfe / max(nst, 1), "nlu_per_step": nlu / max(nst, 1), "nje_per_step": nje / max(nst, 1),

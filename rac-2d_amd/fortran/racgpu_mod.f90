@@ -15,7 +15,7 @@ module racgpu
   public :: racgpu_network_load, racgpu_network_destroy, racgpu_network_dims, racgpu_species_name, &
             racgpu_species_index, racgpu_load_initial_abundances, racgpu_params_default, racgpu_n_record, &
             racgpu_set_tolerances, racgpu_init_abundances, racgpu_set_device, racgpu_device_count, &
-            racgpu_solve_batch, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
+            racgpu_solve_batch, racgpu_set_cost_hints, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
   public :: racgpu_error_string, chemsol_to_c, c_string
 
   integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 16, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
@@ -150,6 +150,14 @@ module racgpu
       integer(c_int64_t), value :: ncell
       type(c_ptr), value :: cells, y, t_final, quality, stats, record, touts
       integer(c_int), value :: mem
+      integer(c_int) :: rc
+    end function
+    ! scheduling hint for the following racgpu_solve_batch calls: expected work per cell, costliest cells first
+    function racgpu_set_cost_hints(h, cost, ncell) bind(c, name='racgpu_set_cost_hints') result(rc)
+      import :: c_ptr, c_double, c_int64_t, c_int
+      type(c_ptr), value :: h
+      real(c_double), dimension(*), intent(in) :: cost
+      integer(c_int64_t), value :: ncell
       integer(c_int) :: rc
     end function
     function racgpu_last_kernel_ms(h) bind(c, name='racgpu_last_kernel_ms') result(ms)
