@@ -14,7 +14,7 @@ constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K
 
 // extents of column j in the U, L and P storage; ur = end of the U entries with rows < ns (the pivots applied through
 // LDS); [d0, d1) = the column's slice of the pivot descriptor stream
-struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, pad[7]; };
+struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, j, pad[6]; }; // j = the column this work item factors
 constexpr int kJacUnroll = 8; // rows of the Jacobian term stream per unrolled step (the stream is padded to a multiple)
 constexpr int kLuDepth = 4; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
 
@@ -59,7 +59,10 @@ struct DevNet {
   // k | len<<16 | (1<<30 if the pivot opens a new level within column j) | start<<32, where [start, start+len) is
   // (a piece of at most 64 rows of) L column k; slices are padded with null descriptors (len 0)
   const unsigned long long *Udesc;
-  const LuCol *lucol;        // [nS+1] per-column extents for the LU (entry nS repeats nS-1: the column prefetch reads one ahead)
+  const LuCol *lucol;        // [nwork+2] the LU's work list (engine.hip, upload): columns with pivots, then the trailing block
+  int nwork_sparse, nwork;   // work items with j < ns / in all
+  const unsigned long long *leaf_diag, *leaf_ent; // pivot-free columns, factored elementwise beforehand
+  int nleaf, nleaf_ent;
   int nchunkL, nchunkU;
   int nzl_stream, nzu_stream; // entries of the streamed parts; the trailing columns follow back to back (closed-form starts)
   // type-11 special indices (0-based, -1 none)

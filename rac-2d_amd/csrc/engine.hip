@@ -344,14 +344,41 @@ void racgpu_network::upload() {
       return rc;
     };
     {
-      std::vector<unsigned long long> ud;
-      std::vector<LuCol> lc(nS + 1);
+      // Work list of the LU: the columns j < ns that have pivots (U(:,j) not empty), ascending, then the trailing
+      // columns ns..n-1.  Columns j < ns WITHOUT pivots ("leaves": nothing is ever subtracted from them) are
+      // factored beforehand in one elementwise pass: D^-1_j = 1/P(j,j), L(:,j) = P(rows > j, j) * D^-1_j, their L
+      // pattern being exactly P's (leaf_diag: position of P(j,j) | j<<32; leaf_ent: position in P | position in L
+      // << 20 | j << 40).
+      std::vector<unsigned long long> ud, leaf_diag, leaf_ent;
+      std::vector<LuCol> lc;
+      int nwork_sparse = 0;
       for (int j = 0; j < nS; ++j) {
-        const int ur = S.Ucolend[j]; // rows < ns only: the pivots ns..j-1 of a trailing column are applied in registers
+        if (j < S.ns && S.Ucolend[j] == S.Ucolptr[j]) {
+          bool pattern_ok = (S.Lcolend[j] - S.Lcolptr[j]) == 0;
+          int nbelow = 0;
+          for (int q = S.Pcolptr[j]; q < S.Pcolptr[j + 1]; ++q) if (S.Prow[q] > j) ++nbelow;
+          pattern_ok = nbelow == S.Lcolend[j] - S.Lcolptr[j];
+          bool has_diag = false, above = false;
+          for (int q = S.Pcolptr[j]; q < S.Pcolptr[j + 1]; ++q) { if (S.Prow[q] == j) has_diag = true; if (S.Prow[q] < j) above = true; }
+          if (pattern_ok && has_diag && !above) {
+            for (int q = S.Pcolptr[j]; q < S.Pcolptr[j + 1]; ++q) {
+              const int r = S.Prow[q];
+              if (r == j) leaf_diag.push_back((unsigned long long)q | ((unsigned long long)j << 32));
+              else {
+                int lp = -1;
+                for (int t = S.Lcolptr[j]; t < S.Lcolend[j]; ++t) if (S.Lrow[t] == r) lp = t;
+                if (lp < 0) throw std::runtime_error("LU layout: leaf column pattern mismatch");
+                leaf_ent.push_back((unsigned long long)q | ((unsigned long long)lp << 20) | ((unsigned long long)j << 40));
+              }
+            }
+            continue;
+          }
+        }
         LuCol c{};
         c.u0 = S.Ucolptr[j]; c.u1 = S.Ucolend[j]; c.lc0 = S.Lcolptr[j]; c.lc1 = S.Lcolend[j]; c.p0 = S.Pcolptr[j]; c.p1 = S.Pcolptr[j + 1];
-        c.ur = ur; c.d0 = (int)ud.size();
-        for (int q = S.Ucolptr[j]; q < ur; ++q) {
+        c.ur = S.Ucolend[j]; // rows < ns only: the pivots ns..j-1 of a trailing column are applied in registers
+        c.d0 = (int)ud.size(); c.j = j;
+        for (int q = S.Ucolptr[j]; q < c.ur; ++q) {
           const int k = S.Urow[q];
           const int len = S.Lcolend[k] - S.Lcolptr[k];
           for (int off = 0; off < std::max(len, 1); off += 64) // L columns longer than 64 rows: one descriptor per 64 rows
@@ -360,11 +387,16 @@ void racgpu_network::upload() {
         }
         while (ud.size() % kLuDepth) ud.push_back(0ull);
         c.d1 = (int)ud.size();
-        lc[j] = c;
+        lc.push_back(c);
+        if (j < S.ns) ++nwork_sparse;
       }
       ud.resize(ud.size() + 64, 0ull);
       dn.Udesc = up(ud);
-      lc[nS] = nS > 0 ? lc[nS - 1] : LuCol{};
+      dn.nwork_sparse = nwork_sparse; dn.nwork = (int)lc.size();
+      dn.nleaf = (int)leaf_diag.size(); dn.nleaf_ent = (int)leaf_ent.size();
+      leaf_diag.resize(leaf_diag.size() + 64, 0ull); leaf_ent.resize(leaf_ent.size() + 64, 0ull);
+      dn.leaf_diag = up(leaf_diag); dn.leaf_ent = up(leaf_ent);
+      lc.push_back(lc.empty() ? LuCol{} : lc.back()); lc.push_back(lc.back()); // the column prefetch reads two ahead
       dn.lucol = up(lc);
     }
     dn.nzl_stream = S.nzl_stream; dn.nzu_stream = S.nzu_stream;

@@ -362,7 +362,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
                bU = mkbuf(Uv);
   const int l2 = lane * 2, l8 = lane * 8; // lane part of every byte offset (u16 and 8-byte arrays)
   const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column
-  auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; return r; };
+  auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; r.j = c[9]; return r; };
   (void)w2;
   for (int i = lane; i < n; i += 64) w[i] = 0.0; // the work column is kept all-zero between columns
   lds_sync();
@@ -372,7 +372,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 
   // one-column-ahead prefetch: extents (scalar), first 64 pivot descriptors, first 64 P entries, first 64 rows of
   // the U and L parts.  All tables and value slices are padded by 64 entries, so these loads are unconditional.
-  LuCol nxc = load_col(0), nx2 = load_col(min(1, n)), cur = nxc; // extents are fetched two columns ahead (scalar loads)
+  LuCol nxc = load_col(0), nx2 = load_col(1), cur = nxc; // extents are fetched two work items ahead (scalar loads; the list is padded by two)
   unsigned long long nx_dq; double nx_pv; uint16_t nx_pr, nx_fu, nx_fl, cu_fu = 0, cu_fl = 0;
   auto prefetch_col = [&]() {
     nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = bload_f64(bP, l8, nxc.p0 * 8); nx_pr = bload_u16(bProw, l2, nxc.p0 * 2);
@@ -390,11 +390,11 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   // so the wave never waits for them either; the LDS executes one wave's operations in issue order, which is what
   // makes the next level's read see them.  L columns are loaded kLuDepth-1 pivots ahead into register sets
   // with static indices (the loop is unrolled by the depth).
-  auto rect_phase = [&](int j, double *wv) {
+  auto rect_phase = [&](int widx, double *wv) { // widx: position in the work list; the column is cur.j afterwards
     cur = nxc; cu_fu = nx_fu; cu_fl = nx_fl;
     const unsigned long long dq0 = nx_dq;
     const double pv = nx_pv; const int pr = nx_pr;
-    nxc = nx2; nx2 = load_col(min(j + 2, n));
+    nxc = nx2; nx2 = load_col(widx + 2);
     prefetch_col();
     if (lane < cur.p1 - cur.p0) wv[pr] = pv;
     for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[bload_u16(bProw, q * 2, 0)] = bload_f64(bP, q * 8, 0); // rare: > 64 entries
@@ -453,14 +453,19 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 
   // ---- column j, last part: pivot, scaled U and L columns to HBM, work column back to zero ------------------------
   auto finish = [&](int j, double *wv) {
+    // all LDS reads of the column's first 64 U and L entries go out together (one wait), then zeroing and stores
     const double d = wv[j];
-    store_u(wv, cur.u1); // needs D^-1 of earlier columns only: the division below overlaps with it
+    const bool hasU = cur.u0 + lane < cur.u1, hasL = cur.lc0 + lane < cur.lc1;
+    const int ku = hasU ? (int)cu_fu : j, il = hasL ? (int)cu_fl : j;
+    const double uv = wv[ku], dk = dl[ku], lv = wv[il];
+    lds_order();
+    if (hasU) { bstore_f64(bU, l8, cur.u0 * 8, uv * dk); wv[ku] = 0.0; }
+    for (int q = cur.u0 + 64 + lane; q < cur.u1; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); bstore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
     if (lane == 0) { Dinv[j] = dinv; dl[j] = dinv; wv[j] = 0.0; }
-    int q = cur.lc0 + lane;
-    if (q < cur.lc1) { const int i = cu_fl; bstore_f64(bL, l8, cur.lc0 * 8, wv[i] * dinv); wv[i] = 0.0; }
-    for (q += 64; q < cur.lc1; q += 64) { const int i = bload_u16(bLrow, q * 2, 0); bstore_f64(bL, q * 8, 0, wv[i] * dinv); wv[i] = 0.0; }
+    if (hasL) { bstore_f64(bL, l8, cur.lc0 * 8, lv * dinv); wv[il] = 0.0; }
+    for (int q = cur.lc0 + 64 + lane; q < cur.lc1; q += 64) { const int i = bload_u16(bLrow, q * 2, 0); bstore_f64(bL, q * 8, 0, wv[i] * dinv); wv[i] = 0.0; }
     wave_sync(); // L, U, Dinv of this column are read back from HBM by later columns
     RG_TICK(c_fin)
   };
@@ -474,8 +479,31 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     return t.d;
   };
 
-  int j = 0;
-  for (; j < n && j < ns; ++j) { rect_phase(j, w); RG_TICK(c_dense) finish(j, w); }
+  // ---- pivot-free columns, all at once: D^-1 = 1/P(j,j), L(:,j) = P(rows > j, j) * D^-1 --------------------------------
+  {
+    const rsrc_t bLd = mkbuf(N.leaf_diag), bLe = mkbuf(N.leaf_ent);
+    for (int q0 = 0; q0 < N.nleaf; q0 += 64) {
+      const unsigned long long e = bload_u64(bLd, l8, q0 * 8);
+      if (q0 + lane < N.nleaf) {
+        const int jj = (int)(e >> 32);
+        const double d = bload_f64(bP, (int)(e & 0xfffff) * 8, 0);
+        if (d == 0.0) ok = false;
+        const double dinv = 1.0 / d;
+        Dinv[jj] = dinv; dl[jj] = dinv;
+      }
+    }
+    lds_sync();
+    for (int q0 = 0; q0 < N.nleaf_ent; q0 += 64) {
+      const unsigned long long e = bload_u64(bLe, l8, q0 * 8);
+      if (q0 + lane < N.nleaf_ent)
+        bstore_f64(bL, (int)((e >> 20) & 0xfffff) * 8, 0, bload_f64(bP, (int)(e & 0xfffff) * 8, 0) * dl[(int)(e >> 40)]);
+    }
+    wave_sync();
+    RG_TICK(c_fin)
+  }
+
+  for (int c = 0; c < N.nwork_sparse; ++c) { rect_phase(c, w); RG_TICK(c_dense) finish(cur.j, w); }
+  int j = ns;
 
   // ---- dense trailing block, G columns at a time -------------------------------------------------------------------
   // After a column's LDS pivots (k < ns) its entries in rows < ns are final and go straight to U; its tail rows
@@ -491,7 +519,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
       wA[c] = 0.0; wB[c] = 0.0;
       if (c < ng) {
         const int jc = j + c;
-        rect_phase(jc, w);
+        rect_phase(N.nwork_sparse + (jc - ns), w);
         store_u(w, cur.ur);
         if (rowA < n) { wA[c] = w[rowA]; w[rowA] = 0.0; }
         if (rowB < n) { wB[c] = w[rowB]; w[rowB] = 0.0; }
