@@ -97,7 +97,8 @@ class Network:
         self.vib_freq = np.ctypeslib.as_array(n.vib_freq, (self.nS,)).copy()
         self.Edesorb = np.ctypeslib.as_array(n.Edesorb, (self.nS,)).copy()
         self.counterpart = np.ctypeslib.as_array(n.counterpart, (self.nS,)).copy()
-        self.charge = np.ctypeslib.as_array(n.elements, (self.nS, 20))[:, 0].copy()
+        self.elements = np.ctypeslib.as_array(n.elements, (self.nS, 20)).copy()  # getElements: column 0 = charge, then the 19 elements
+        self.charge = self.elements[:, 0].copy()
         self.IA = np.ctypeslib.as_array(n.IA, (self.NEQ + 1,)).copy()
         self.JA = np.ctypeslib.as_array(n.JA, (self.NNZ,)).copy()
         self.i_Grain0 = n.i_Grain0

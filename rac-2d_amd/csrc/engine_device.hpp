@@ -435,8 +435,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
           src.d = tvv;
           tv.w[0] = __builtin_amdgcn_readlane(src.w[0], tt);
           tv.w[1] = __builtin_amdgcn_readlane(src.w[1], tt);
-          if (lane < z[s]) atomicAdd(&wv[i[s]], -(l[s] * tv.d));
-          lds_order();
+          if (lane < z[s]) atomicAdd(&wv[i[s]], -(l[s] * tv.d)); // (program order of LDS accesses is kept by the compiler: may-alias)
         }
       }
 #undef RG_LU_ISSUE
