@@ -16,6 +16,7 @@ constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K
 // LDS); [d0, d1) = the column's slice of the pivot descriptor stream
 struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, j, pad[6]; }; // j = the column this work item factors
 constexpr int kJacUnroll = 8; // rows of the Jacobian term stream per unrolled step (the stream is padded to a multiple)
+constexpr int kSweepDepth = 4; // chunks of a triangular-solve stream in flight; the schedules are padded to a multiple
 constexpr int kLuDepth = 4; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
 
 struct DevNet {
@@ -52,8 +53,8 @@ struct DevNet {
   const uint16_t *Lrow, *Urow, *Prow;
   const int *Ppos;            // CSC entry -> position in the permuted-column storage of P
   const uint8_t *Pdiag;       // [nnzJ] in storage order: 1 on the diagonal
-  // triangular-solve schedules: one packed word per stored entry, row | col<<10 | level<<20, padded to a multiple
-  // of 64 with row == col (skipped) carrying the last level
+  // triangular-solve schedules: one packed word per stored entry of the streamed part, row | col<<10 |
+  // (next chunk continues this level)<<20; chunks of 64 entries hold one dependency level each; null: row == col
   const uint32_t *Lrc, *Urc;
   // LU pivot descriptors, per column j one slice [d0, d1): for every pivot k < ns of the column, in U storage order,
   // k | len<<16 | (1<<30 if the pivot opens a new level within column j) | start<<32, where [start, start+len) is

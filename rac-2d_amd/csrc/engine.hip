@@ -335,12 +335,22 @@ void racgpu_network::upload() {
       dn.Pdiag = up(pd);
     }
     auto pack = [](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, size_t nstream, int &nchunk) {
-      std::vector<uint32_t> rc(nstream); // the streamed part only: the dense trailing block is solved in registers
-      for (size_t e = 0; e < nstream; ++e) rc[e] = (uint32_t)row[e] | ((uint32_t)col[e] << 10) | ((uint32_t)lev[e] << 20);
-      const uint32_t padlev = nstream == 0 ? 0u : (uint32_t)lev[nstream - 1];
-      rc.resize((nstream + 63) / 64 * 64, padlev << 20); // row == col == 0: skipped
-      nchunk = (int)(rc.size() / 64);
-      rc.resize(rc.size() + 16 * 64, padlev << 20); // spare chunks: the sweep prefetches unconditionally, up to 15 chunks ahead
+      // the streamed part only (the dense trailing block is solved in registers); the storage is level-aligned, so
+      // every chunk of 64 entries has ONE level; bit 20 of every word of a chunk: the next chunk continues this level
+      std::vector<uint32_t> rc(nstream);
+      for (size_t e = 0; e < nstream; ++e) rc[e] = (uint32_t)row[e] | ((uint32_t)col[e] << 10);
+      rc.resize((nstream + 63) / 64 * 64, 0u); // row == col == 0: skipped
+      size_t nch = rc.size() / 64;
+      auto chunk_level = [&](size_t c) { return lev[std::min(c * 64, nstream - 1)]; };
+      for (size_t c = 0; c < nch; ++c) {
+        for (size_t e = c * 64; e < std::min((c + 1) * 64, nstream); ++e)
+          if (lev[e] != chunk_level(c)) throw std::runtime_error("solve schedule: a chunk spans two levels");
+        if (c + 1 < nch && chunk_level(c + 1) == chunk_level(c))
+          for (size_t e = c * 64; e < (c + 1) * 64; ++e) rc[e] |= 1u << 20;
+      }
+      while (nch % kSweepDepth) { rc.resize(rc.size() + 64, 0u); ++nch; } // null chunks: the sweep is unrolled by its depth
+      nchunk = (int)nch;
+      rc.resize(rc.size() + 16 * 64, 0u); // spare chunks: the sweep prefetches unconditionally
       return rc;
     };
     {
@@ -520,8 +530,8 @@ int racgpu_network_dims(const racgpu_network *h, int32_t *nS, int32_t *nR, int32
   if (nS) *nS = h->net.nS;
   if (nR) *nR = h->net.nR;
   if (nnzJ) *nnzJ = (int32_t)h->net.Jrow.size();
-  if (nzl) *nzl = h->net.sym.nzl;
-  if (nzu) *nzu = h->net.sym.nzu;
+  if (nzl) *nzl = h->net.sym.nzl_entries; // entries of the factors (the storage also holds alignment padding)
+  if (nzu) *nzu = h->net.sym.nzu_entries;
   return 0;
 }
 

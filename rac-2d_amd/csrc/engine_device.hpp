@@ -327,9 +327,6 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
   wave_sync();
 }
 
-#ifndef RG_TS_DEPTH
-#define RG_TS_DEPTH 4
-#endif
 RG_DEV void lds_order() {
   // Hot-loop variant of lds_sync: only pins the instruction order.  The LDS executes one wave's operations in
   // issue order, and every access it separates goes through a run-time index into the same array, so the
@@ -591,34 +588,36 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   return ok;
 }
 
-// One triangular sweep: entries stream in level order, 64 per step; every entry does x[row] -= v * x[col].
-// Within a level the columns are independent; entries of different columns may hit the same row, hence the
-// LDS atomic.  The next 64 entries are in flight while the current ones are applied.
-template <int D>
+// One triangular sweep over the streamed part: entries come in dependency-level order, 64 per chunk, one level per
+// chunk (the storage is level-aligned); every entry does x[row] -= v * x[col].  Within a level the columns are
+// independent; entries of different columns may hit the same row, hence the LDS atomic (no return: the wave never
+// waits for it).  Schedule words and values are kSweepDepth-1 chunks ahead in registers; the x[col] of the next
+// chunk are read from LDS before this chunk's updates are issued whenever that chunk continues the level, so a
+// level costs one LDS round trip, not one per chunk.
 RG_DEV void dev_tri_sweep(const uint32_t *__restrict__ rc, const double *__restrict__ val, int nchunk, double *w, int lane) {
   if (nchunk <= 0) return;
-  // D register sets with static indices (the loop is unrolled by D), D-1 chunks in flight: HBM latency is ~900
-  // cycles and a chunk applies in ~150, so the stream has to run many chunks ahead.  The schedule and the value
-  // slices are padded (D chunks) so every prefetch is unconditional.
+  constexpr int D = kSweepDepth;
   uint32_t r[D];
   double v[D];
   const rsrc_t brc = mkbuf(rc), bval = mkbuf(val);
   const int l4 = lane * 4, l8 = lane * 8;
 #pragma unroll
   for (int s = 0; s < D - 1; ++s) { r[s] = bload_u32(brc, l4, s * 256); v[s] = bload_f64(bval, l8, s * 512); }
-  for (int c = 0; c < nchunk; c += D) {
+  double x = 0.0;
+  bool have = false; // x already holds this chunk's x[col] (read while the previous chunk of the same level was applied)
+  for (int c = 0; c < nchunk; c += D) { // nchunk is a multiple of D (null chunks at the end)
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-      if (c + s < nchunk) {
-        const int sl = (s + D - 1) % D; // the set applied one sub-step ago is free again
-        r[sl] = bload_u32(brc, l4, (c + s + D - 1) * 256); v[sl] = bload_f64(bval, l8, (c + s + D - 1) * 512);
-        const int row = (int)(r[s] & 1023u), col = (int)((r[s] >> 10) & 1023u), lev = (int)(r[s] >> 20);
-        const int lfirst = __builtin_amdgcn_readfirstlane(lev), llast = __builtin_amdgcn_readlane(lev, 63);
-        for (int l = lfirst; l <= llast; ++l) {
-          if (lev == l && row != col) atomicAdd(&w[row], -(v[s] * w[col]));
-          lds_order();
-        }
-      }
+      const int sl = (s + D - 1) % D; // the set applied one sub-step ago is free again
+      r[sl] = bload_u32(brc, l4, (c + s + D - 1) * 256); v[sl] = bload_f64(bval, l8, (c + s + D - 1) * 512);
+      const uint32_t wd = r[s], wn = r[(s + 1) % D];
+      const int row = (int)(wd & 1023u), col = (int)((wd >> 10) & 1023u);
+      const bool cont = (__builtin_amdgcn_readfirstlane((int)wd) >> 20) & 1;
+      if (!have) { lds_order(); x = w[col]; }
+      double xn = 0.0;
+      if (cont) xn = w[(wn >> 10) & 1023u];
+      if (row != col) atomicAdd(&w[row], -(v[s] * x));
+      have = cont; x = xn;
     }
   }
 }
@@ -629,7 +628,7 @@ RG_DEV void dev_tri_sweep(const uint32_t *__restrict__ rc, const double *__restr
 // with one contiguous load per half, RG_DS_DEPTH columns in flight.  Loads are unconditional (row index clamped into
 // the column), the unused lanes are switched off by a select, so the loops are free of branches.
 #ifndef RG_DS_DEPTH
-#define RG_DS_DEPTH 4
+#define RG_DS_DEPTH 8
 #endif
 RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const double *__restrict__ Uv, const double *__restrict__ Dinv,
                       double *x, double *w, int lane) {
@@ -637,7 +636,7 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
   lds_sync();
   for (int i = lane; i < n; i += 64) w[i] = x[gptr(N.perm)[i]];
   lds_sync();
-  dev_tri_sweep<RG_TS_DEPTH>(N.Lrc, Lv, N.nchunkL, w, lane); // columns k < ns
+  dev_tri_sweep(N.Lrc, Lv, N.nchunkL, w, lane); // columns k < ns
   lds_sync();
   const int rowA = ns + lane, rowB = ns + 64 + lane, rA8 = rowA * 8, rB8 = rowB * 8;
   const bool hasA = rowA < n, hasB = rowB < n;
@@ -707,7 +706,7 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
   if (hasA) w[rowA] = xA;
   if (hasB) w[rowB] = xB;
   lds_sync();
-  dev_tri_sweep<RG_TS_DEPTH>(N.Urc, Uv, N.nchunkU, w, lane); // rows < ns of every column
+  dev_tri_sweep(N.Urc, Uv, N.nchunkU, w, lane); // rows < ns of every column
   for (int i = lane; i < n; i += 64) x[gptr(N.perm)[i]] = w[i];
   lds_sync();
 }

@@ -423,7 +423,15 @@ void build_symbolic(HostNetwork &net) {
     return order;
   };
   S.Lcolptr.assign(n, 0); S.Lcolend.assign(n, 0); S.Lrow.clear(); S.Lcol.clear(); S.Llev.clear(); S.nlevL = 0;
+  // a chunk of 64 stream entries never spans two levels: when the level changes the stream is padded to a multiple of
+  // 64 with null entries (row == col == 0; their value slots are never written nor used)
+  auto pad_level = [](std::vector<int> &row, std::vector<int> &col, std::vector<int> &lev, int newlev) {
+    if (row.empty() || lev.back() == newlev) return;
+    const int l = lev.back();
+    while (row.size() % 64) { row.push_back(0); col.push_back(0); lev.push_back(l); }
+  };
   for (int k : level_order(llev, S.ns, false)) {
+    if (!Lc[k].empty()) pad_level(S.Lrow, S.Lcol, S.Llev, llev[k]);
     S.Lcolptr[k] = (int)S.Lrow.size();
     for (int i : Lc[k]) { S.Lrow.push_back(i); S.Lcol.push_back(k); S.Llev.push_back(llev[k]); }
     S.Lcolend[k] = (int)S.Lrow.size();
@@ -437,6 +445,7 @@ void build_symbolic(HostNetwork &net) {
   }
   S.Ucolptr.assign(n, 0); S.Ucolend.assign(n, 0); S.Udptr.assign(n, 0); S.Urow.clear(); S.Ucol.clear(); S.Ulev.clear(); S.nlevU = 0;
   for (int k : level_order(ulev, n, true)) {
+    { bool any = false; for (int i : Uc[k]) if (i < S.ns) any = true; if (any) pad_level(S.Urow, S.Ucol, S.Ulev, ulev[k]); }
     S.Ucolptr[k] = (int)S.Urow.size();
     for (int i : Uc[k]) if (i < S.ns) { S.Urow.push_back(i); S.Ucol.push_back(k); S.Ulev.push_back(ulev[k]); }
     S.Ucolend[k] = (int)S.Urow.size();
@@ -448,6 +457,8 @@ void build_symbolic(HostNetwork &net) {
     for (int i = S.ns; i < k; ++i) { S.Urow.push_back(i); S.Ucol.push_back(k); S.Ulev.push_back(0); }
   }
   S.nzl = (int)S.Lrow.size(); S.nzu = (int)S.Urow.size();
+  S.nzl_entries = 0; S.nzu_entries = 0; // without the alignment padding
+  for (int k = 0; k < n; ++k) { S.nzl_entries += (int)Lc[k].size(); S.nzu_entries += (int)Uc[k].size(); }
   S.Ugrp.assign(S.nzu, 0);
   for (int j = 0; j < n; ++j) for (int a = 0; a < S.Ucolend[j] - S.Ucolptr[j]; ++a) S.Ugrp[S.Ucolptr[j] + a] = Uflag[j][a];
   if (n > 1023 || S.nlevL > 4094 || S.nlevU > 4094)

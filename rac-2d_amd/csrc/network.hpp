@@ -56,7 +56,8 @@ struct Symbolic { // LU structure of P = I - gamma*J on the species block, cell 
   // P is STORED in permuted-column order (column j' = perm^-1 of species column, rows ascending): Pcolptr/Prow
   // describe that storage; Psrc[q] = CSC entry held at position q, Ppos = its inverse
   std::vector<int> Pcolptr, Psrc, Prow, Ppos;
-  int nzl = 0, nzu = 0;
+  int nzl = 0, nzu = 0;                 // storage sizes of L and U (with the level-alignment padding of the streamed parts)
+  int nzl_entries = 0, nzu_entries = 0; // entries of the factors proper
 };
 
 struct HostNetwork {
