@@ -417,7 +417,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     i[S] = bload_u16(bLrow, l2, a[S] * 2); l[S] = bload_f64(bL, l8, a[S] * 8);                                     \
   }
 #pragma unroll
-      for (int s = 0; s < D - 1; ++s) RG_LU_ISSUE(s, s)
+      for (int s = 0; s < D - 1; ++s) { RG_LU_ISSUE(s, s) __builtin_amdgcn_sched_barrier(0); } // keep the issue order: data returns in order
       for (int t = 0; t < nk; t += D) {
 #pragma unroll
         for (int s = 0; s < D; ++s) {
