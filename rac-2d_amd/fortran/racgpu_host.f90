@@ -11,6 +11,10 @@
 !                      reference src/data_dump.f90:88-162; the 20 column densities belong to the caller: zeros)
 !   <out_prefix>.dat : one row per cell: t_final, quality, NST, then abundances in ES14.5E3 under an A14 header
 !                      (the trailing columns of the reference's iter_NNNN.dat, src/disk.f90:2749-2750, 3072)
+!   with flag_chem_evol_save = .true. in the namelist, per cell i also
+!   <out_prefix>_cellNNNNNN_<chem_evol_save_filename> : the time series chem_evol_solve writes while it integrates
+!                      (reference src/chemistry.f90:404-413, 476-478): header '! Time', species names, 'Tgas' in A14,
+!                      then one row (t, y(1:NEQ)) in ES14.4E4 per record 2..n_record_real
 program racgpu_host
   use, intrinsic :: iso_c_binding
   use racgpu
@@ -21,7 +25,10 @@ program racgpu_host
   type(c_ptr) :: net
   type(racgpu_params_t) :: p
   integer(c_int32_t) :: nS, nR, nnzJ, nzl, nzu
-  integer :: fu, ios, ncell, i, k, rc, reclen
+  integer :: fu, ios, ncell, i, k, rc, reclen, n_record, nrr
+  real(c_double), allocatable, target :: record(:, :, :), touts(:, :)
+  type(c_ptr) :: prec, ptouts
+  character(len=16) :: tag
   real(c_double), allocatable, target :: cells(:, :), y(:, :), y0(:), t_final(:)
   integer(c_int32_t), allocatable, target :: quality(:)
   integer(c_int64_t), allocatable, target :: stats(:, :)
@@ -90,8 +97,14 @@ program racgpu_host
   close(fu)
 
   rc = racgpu_init_abundances(net, y0, cells, int(ncell, c_int64_t), y)
+  prec = c_null_ptr; ptouts = c_null_ptr
+  n_record = racgpu_n_record(p, 0D0, p%t_max)
+  if (chemsol_params%flag_chem_evol_save) then ! chemsol_stor%record / %touts of every cell (1.2 MB per cell)
+    allocate(record(nS + 1, n_record, ncell), touts(n_record, ncell))
+    prec = c_loc(record); ptouts = c_loc(touts)
+  end if
   rc = racgpu_solve_batch(net, p, int(ncell, c_int64_t), c_loc(cells), c_loc(y), c_loc(t_final), c_loc(quality), &
-                          c_loc(stats), c_null_ptr, c_null_ptr, RACGPU_MEM_HOST)
+                          c_loc(stats), prec, ptouts, RACGPU_MEM_HOST)
   if (rc /= 0) then
     write(*, '(A)') 'racgpu_solve_batch: ' // trim(racgpu_error_string())
     stop 1
@@ -113,5 +126,19 @@ program racgpu_host
     write(fu, fmt) t_final(i), quality(i), int(stats(1, i)), y(:, i)
   end do
   close(fu)
+  if (chemsol_params%flag_chem_evol_save) then
+    do i = 1, ncell
+      write(tag, '("_cell", I6.6, "_")') i
+      open(newunit=fu, file=trim(prefix) // trim(tag) // trim(chemsol_params%chem_evol_save_filename), status='replace')
+      write(fmt, '("(", I4, "A14)")') nS + 2
+      write(fu, fmt) '! Time        ', names(1:nS), '   Tgas       '
+      write(fmt, '("(", I4, "ES14.4E4)")') nS + 2
+      nrr = int(stats(6, i)) ! RACGPU_S_NREC_REAL: chemsol_params%n_record_real
+      do k = 2, min(nrr, n_record)
+        write(fu, fmt) touts(k, i), record(:, k, i)
+      end do
+      close(fu)
+    end do
+  end if
   call racgpu_network_destroy(net)
 end program racgpu_host

@@ -35,6 +35,38 @@ def test_fortran_host_matches_reference(tmp_path, racgpu):
     assert hdr[3:] == list(g["species"])
 
 
+@pytest.mark.gpu
+def test_fortran_host_writes_the_time_series_of_chem_evol_solve(tmp_path, racgpu):
+    """flag_chem_evol_save = .true.: the file chem_evol_solve writes while integrating (reference
+    src/chemistry.f90:404-413, 476-478): '! Time', names, 'Tgas' in A14; rows (t, y(1:NEQ)) in ES14.4E4 for the records
+    2..n_record_real.  Checked against the reference's own record of the same cell (golden touts and end state)."""
+    if not os.path.exists(HOST):
+        pytest.skip("racgpu_host not built")
+    g = load_golden("rate06_nograin")
+    np.savetxt(tmp_path / "cells.txt", g["cells"][:1], fmt="%.17e")
+    conf = open(os.path.join(ROOT, "tests", "fortran_host", "configure_chemistry.dat")).read()
+    conf = conf.replace("flag_chem_evol_save         = .false.", "flag_chem_evol_save         = .true. ")
+    assert ".true." in conf
+    (tmp_path / "conf.dat").write_text(conf)
+    out = subprocess.run([HOST, str(tmp_path / "conf.dat"), str(tmp_path / "cells.txt"), str(tmp_path / "out")],
+                         cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = open(tmp_path / "out_cell000001_chem_evol_tmp.dat").read().splitlines()
+    nS = 464
+    hdr = [rows[0][14 * k:14 * (k + 1)] for k in range(nS + 2)]
+    assert hdr[0] == "! Time        " and hdr[-1] == "   Tgas       " and [h.strip() for h in hdr[1:-1]] == list(g["species"])
+    touts = g["touts"][0]
+    assert len(rows) - 1 == len(touts) - 1 == 315  # records 2..316 (the initial state is not written)
+    assert all(len(r) == 14 * (nS + 2) for r in rows[1:])
+    data = np.array([[float(r[14 * k:14 * (k + 1)]) for k in range(nS + 2)] for r in rows[1:]])
+    np.testing.assert_allclose(data[:, 0], touts[1:], rtol=6e-5)   # ES14.4E4: five significant digits
+    assert np.all(data[:, -1] == g["cells"][0, 0])                    # the T slot stays at Tgas (fixed-T branch)
+    ref = g["yend"][0][:nS]
+    m = ref >= 1e-6
+    floor = major_relerr(g["yend_ulp"][0][:nS], ref)
+    assert np.max(np.abs(data[-1, 1:-1][m] - ref[m]) / ref[m]) <= max(1e-4, 3 * floor) + 6e-5
+
+
 def test_fortran_host_reads_reference_namelist_without_gpu(tmp_path, racgpu):
     """No GPU: the host must parse the namelist and then refuse loudly (exit code 1, message)."""
     if racgpu.device_count() > 0 or not os.path.exists(HOST):
