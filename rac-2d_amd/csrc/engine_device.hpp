@@ -263,18 +263,18 @@ RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double ns
 RG_DEV double dev_dflux(uint64_t term, double k, const RG_GLOBAL double *__restrict__ r_C, double nsite, const double *y) {
   const int rxn = (int)(term & 0xffff), sa = (int)((term >> 16) & 0xffff), kind = (int)((term >> 32) & 0xff);
   const int flags = (int)((term >> 40) & 0xff), sb = (int)((term >> 48) & 0xffff);
-  double v;
-  if (kind == K_TWO_) {
-    const double ya = y[sa], yb = y[sb];
-    if (flags & 2) v = 2.0 * k * yb;
-    else v = (flags & 4) ? k * yb : k * ya;
-    if (ya < 0.0 && yb < 0.0) v = -v;
-  } else if (kind == K_ONE_) v = k;
-  else if (kind == K_SQ_) { const double ya = y[sa]; v = 2.0 * k * ya; if (ya < 0.0) v = -v; }
-  else {
+  // sa and sb are valid species indices for every kind (network.cpp), so both abundances are read up front and the
+  // common forms are selected without branching; only the surface-layer forms (62, 75) branch
+  const double ya = y[sa], yb = y[sb];
+  double v2 = (flags & 2) ? 2.0 * k * yb : ((flags & 4) ? k * yb : k * ya); // two-body: d/dy of k*ya*yb
+  if (ya < 0.0 && yb < 0.0) v2 = -v2;
+  double vq = 2.0 * k * ya; // A + A
+  if (ya < 0.0) vq = -vq;
+  double v = (kind == K_TWO_) ? v2 : ((kind == K_SQ_) ? vq : k);
+  if (kind == K_SURF_ || kind == K_SURF75_) {
     double t2 = nsite; if (kind == K_SURF75_) t2 = t2 * r_C[rxn];
     if (t2 <= 0.0) v = 0.0;
-    else { const double t1 = 1.0 / t2, t = y[sa] * t1; v = (t <= 1e-4) ? k * t1 : k * t1 * exp(-t); }
+    else { const double t1 = 1.0 / t2, t = ya * t1; v = (t <= 1e-4) ? k * t1 : k * t1 * exp(-t); }
   }
   return (flags & 1) ? -v : v;
 }
