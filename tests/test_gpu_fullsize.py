@@ -85,3 +85,45 @@ def test_a_cell_does_not_care_where_or_when_it_is_solved(full, racgpu):
     np.testing.assert_array_equal(again["y"], out["y"])
     np.testing.assert_array_equal(again["stats"][:, :8], out["stats"][:, :8])
     np.testing.assert_array_equal(again["quality"], out["quality"])
+
+
+# ---- the other three networks of BASELINE.json (charged grains, itype 21; 484-524 species), 256 synthetic cells each --------
+OTHER = [("rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "ini_abund_waterice_loMetal.dat"),
+         ("rate06_withgrain_lowH2Bind_hiOBind_lowCObind.dat", "ini_abund_waterice_loMetal_CO.dat"),
+         ("rate12_withGrain_lowH2Bind_hiObind.dat", "ini_abund_waterice_loMetal.dat")]
+
+
+@pytest.mark.parametrize("netfile,inifile", OTHER, ids=["rate06_grain", "rate06_default", "rate12_grain"])
+def test_other_networks_batch_properties(racgpu, oracle, netfile, inifile):
+    """Same properties on the with-grain networks: completion or flags, conservation of every balanced column of the
+    element matrix (charge included: the grain charge states take part), independence of the batch position."""
+    net = racgpu.Network(f"{DATA}/{netfile}")
+    y0 = net.load_initial_abundances(f"{DATA}/{inifile}")
+    n = 256
+    cells = racgpu.cells.synth_batch(n, seed=77)
+    p = racgpu.default_params()
+    yin = net.init_abundances(y0, cells)
+    out = net.evol_solve_batch(p, cells, yin)
+    q, tf = out["quality"], out["t_final"]
+    done = (q == 0) & (tf == p.t_max)
+    assert done.sum() >= 0.97 * n, (int(done.sum()), np.unique(q, return_counts=True))
+    assert np.all(tf[(q == 0) & ~done] > 0.5 * p.t_max)
+    onet = oracle.Network(f"{DATA}/{netfile}")
+    el = onet.elements.astype(np.float64)
+    balance = np.zeros((onet.nR, el.shape[1]))
+    for k in range(3):
+        m = onet.reac[:, k] > 0
+        balance[m] -= el[onet.reac[m, k] - 1]
+    for k in range(4):
+        m = onet.prod[:, k] > 0
+        balance[m] += el[onet.prod[m, k] - 1]
+    balanced = [e for e in range(el.shape[1]) if np.any(el[:, e]) and not np.any(balance[:, e])]
+    assert len(balanced) >= 8, balanced
+    before, after = yin @ el, out["y"] @ el
+    tot = np.maximum(np.abs(yin) @ np.abs(el), np.abs(out["y"]) @ np.abs(el))
+    for e in balanced:
+        drift = np.abs(after[done, e] - before[done, e])
+        bound = 1e-6 * tot[done, e] + 1e-7
+        assert np.all(drift <= bound), (e, float(drift.max()), float((drift / bound).max()))
+    alone = net.evol_solve_batch(p, cells[100:108], yin[100:108])
+    np.testing.assert_array_equal(alone["y"], out["y"][100:108])
