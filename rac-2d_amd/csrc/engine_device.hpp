@@ -501,12 +501,12 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   for (int c = 0; c < N.nwork_sparse; ++c) { rect_phase(c, w); RG_TICK(c_dense) finish(cur.j, w); }
   int j = ns;
 
-  // ---- dense trailing block, G columns at a time -------------------------------------------------------------------
+  // ---- dense trailing block, G columns at a time (G = 8: every L column of the block is read n/8 times, not n times) ----
   // After a column's LDS pivots (k < ns) its entries in rows < ns are final and go straight to U; its tail rows
   // (ns+lane, ns+64+lane) move to registers and stay there.  Pivot k >= ns reads its multiplier from the lane that
   // owns row k (v_readlane) and its L column (rows k+1..n-1, contiguous) with one load that serves all G columns.
   // Nothing of this phase touches LDS except the D^-1 copy; results are stored from registers.
-  constexpr int G = 4;
+  constexpr int G = 8;
   for (; j < n; j += G) {
     const int ng = min(G, n - j);
     double wA[G], wB[G];
