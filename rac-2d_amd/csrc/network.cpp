@@ -357,7 +357,7 @@ void build_symbolic(HostNetwork &net) {
         rows[(size_t)i * W + w] |= m;
       }
     }
-  // Trailing dense block: the widest m <= 128 whose m x m corner of the filled pattern is >= 80 % dense; the
+  // Trailing dense block: the widest m <= 128 whose m x m corner of the filled pattern is >= 90 % dense; the few
   // missing positions are added as explicit zeros (they stay exactly zero numerically).
   {
     int best = n;
@@ -365,7 +365,7 @@ void build_symbolic(HostNetwork &net) {
       const int s0 = n - m;
       long cnt = 0;
       for (int i = s0; i < n; ++i) for (int j = s0; j < n; ++j) cnt += bit(rows, i, j) ? 1 : 0;
-      if ((double)cnt >= 0.80 * (double)m * (double)m) { best = s0; break; }
+      if ((double)cnt >= 0.90 * (double)m * (double)m) { best = s0; break; }
     }
     S.ns = best;
     for (int i = S.ns; i < n; ++i) for (int j = S.ns; j < n; ++j) set(rows, i, j);

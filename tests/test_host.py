@@ -61,9 +61,8 @@ def test_pattern_is_reference_pattern_minus_structural_zeros(racgpu, tag):
     for key in ref - ours:
         assert g["jac0"][pos[key]] == 0.0
     # fill of our ordering vs YSMP's on the reference pattern (IWORK(25), IWORK(26)).  Ours has fewer rows/cols but
-    # pads the trailing block (<= 128 wide, >= 80 % dense) to fully dense with explicit zeros, which costs up to
-    # 0.2 * 128^2 = 3.3 k entries on top of a fill that is otherwise within 4 % of YSMP's: allow 12 %.
-    assert net.nzl + net.nzu <= 1.12 * (g["stats"][0, 5] + g["stats"][0, 6])
+    # pads the trailing block (<= 128 wide, >= 90 % dense) to fully dense with explicit zeros: allow 8 %.
+    assert net.nzl + net.nzu <= 1.08 * (g["stats"][0, 5] + g["stats"][0, 6])
 
 
 def test_n_record_and_defaults(racgpu):
