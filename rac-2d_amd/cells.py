@@ -43,3 +43,16 @@ def synth_batch(ncell, seed=20240601):
         out[i] = make_cell(T[i], min(T[i], 1500.0), n[i], av[i], g0[i],
                            f_H2=min(1.0, 1e-4 / av[i]), f_CO=min(1.0, 1e-2 / av[i]))
     return out
+
+
+def tmax_this(omega_kepler, t_max0=1e6, n_orbit_tmax=1e5, use_fixed_tmax=False):
+    """Per-cell integration time of the caller's sweep (reference set_initial_condition_4solver, src/disk.f90:2017-2018,
+    2078-2085): t_max0 itself with use_fixed_tmax, else min(t_max0, max(100 yr, nOrbit_tmax orbital periods)); omega_kepler
+    in rad/s (par%omega_Kepler), result in years (the reference's year is 365 days).  Goes into slot P_TMAX of the cell
+    record; 0 there means "params.t_max"."""
+    omega = np.asarray(omega_kepler, dtype=np.float64)
+    if use_fixed_tmax:
+        return np.full_like(omega, float(t_max0))
+    seconds_per_year = 3600.0 * 24.0 * 365.0
+    two_pi = 6.283185307179586476925
+    return np.minimum(float(t_max0), np.maximum(1e2, n_orbit_tmax * two_pi / omega / seconds_per_year))

@@ -110,3 +110,14 @@ def test_ragged_and_comment_rows(racgpu, tmp_path):
     at = net.species_attrs()
     assert at["Edesorb"][4] == 450.0 and at["counterpart"][4] == 2 and at["counterpart"][1] == 5
     assert at["charge"].tolist() == [0, 0, 1, -1, 0]
+
+
+def test_per_cell_tmax_orbit_rule(racgpu):
+    """reference src/disk.f90:2078-2085: min(t_max0, max(100, nOrbit_tmax * 2 pi / Omega / yr)) unless use_fixed_tmax."""
+    yr = 3600.0 * 24.0 * 365.0
+    omega_1au = 2 * np.pi / (365.25 * 86400.0)  # ~1.99e-7 rad/s
+    t = racgpu.cells.tmax_this(np.array([omega_1au, omega_1au * 1e6, omega_1au * 1e-3]), t_max0=1e6, n_orbit_tmax=1e5)
+    assert t[0] == pytest.approx(1e5 * 365.25 * 86400.0 / yr) and t[0] < 1e6   # 1e5 orbits at 1 AU ~ 1.0007e5 yr
+    assert t[1] == 1e2                                                           # floor t_min = 100 yr
+    assert t[2] == 1e6                                                           # capped by t_max0
+    assert np.all(racgpu.cells.tmax_this(np.array([omega_1au]), t_max0=3e5, use_fixed_tmax=True) == 3e5)
