@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   long long cyc[4] = {0, 0, 0, 0}, c_lu = 0, c_solve = 0;
   for (int r = 0; r < repeat; ++r) {
     const long long t0 = (long long)__builtin_readcyclecounter();
-    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.acor, v.y, lane, cyc);
+    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.y, lane, cyc);
     const long long t1 = (long long)__builtin_readcyclecounter();
     for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
     dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);

@@ -348,8 +348,8 @@ RG_DEV void lds_sync() {
 // Everything a column needs first (its extents, its P entries, its pivot descriptors, the row lists of its U and
 // L parts) is fetched while the previous column is being worked on.
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
-                   double *__restrict__ Dinv, double *w, double *w2, double *dl, int lane, long long *cyc = nullptr) {
-  // w: LDS work column (w2: spare LDS vector, unused);
+                   double *__restrict__ Dinv, double *w, double *dl, int lane, long long *cyc = nullptr) {
+  // w: LDS work column;
   // dl: LDS copy of D^-1 (the U columns are scaled by it, and a gather from LDS beats one from HBM)
   bool ok = true;
   long long c_scatter = 0, c_rect = 0, c_dense = 0, c_fin = 0, tq = 0;
@@ -360,7 +360,6 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   const int l2 = lane * 2, l8 = lane * 8; // lane part of every byte offset (u16 and 8-byte arrays)
   const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column
   auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; r.j = c[9]; return r; };
-  (void)w2;
   for (int i = lane; i < n; i += 64) w[i] = 0.0; // the work column is kept all-zero between columns
   lds_sync();
   // the trailing columns are stored back to back in index order, so their starts have closed forms (scalar ALU)

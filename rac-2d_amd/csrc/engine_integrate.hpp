@@ -124,7 +124,7 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   }
   s.nlu++; s.con0 = con; s.ierpj = 0;
   wave_sync();
-  { const long long t0 = dev_clock(); if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.acor, c.y, c.lane, c.cyc_lu_part)) s.ierpj = 1; c.cyc_lu += dev_clock() - t0; }
+  { const long long t0 = dev_clock(); if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, c.cyc_lu_part)) s.ierpj = 1; c.cyc_lu += dev_clock() - t0; }
   s.ierpj = uniform_i(wave_any(s.ierpj != 0) ? 1 : 0);
 }
 
