@@ -53,8 +53,10 @@ typedef struct racgpu_params {
   double t_max;                 /* %t_max   [yr]                                           */
   double dt_first_step;         /* %dt_first_step [yr]                                     */
   double ratio_tstep;           /* %ratio_tstep                                            */
-  double max_runtime_allowed;   /* accepted for namelist compatibility; NOT used: the CPU-time guards of
-                                   src/chemistry.f90:480-491 are replaced by max_steps_per_cell */
+  double max_runtime_allowed;   /* %max_runtime_allowed [s]: drives the guards of src/chemistry.f90:438,480-491 ("Premature
+                                   finish", forced ISTATE=1 after a slow interval), applied to MODELLED reference CPU time
+                                   = rt_cost_f*NFE + rt_cost_jac*NJE + rt_cost_lu*NLU (the reference reads the wall clock,
+                                   which no batched engine can reproduce); <= 0 switches the guards off */
   double Diff2DesorRatio;       /* %Diff2DesorRatio (default 0.5)                          */
   double special_gH_E_diff;     /* %special_gH_E_diff (default 225)                        */
   int32_t mxstep_per_interval;  /* %mxstep_per_interval -> DLSODES MXSTEP (IWORK(6))       */
@@ -65,16 +67,36 @@ typedef struct racgpu_params {
   int32_t tol_policy_j;         /* j of chem_set_solver_flags_alt(j) (src/chemistry.f90:205); 1 = as configured */
   int64_t max_steps_per_cell;   /* deterministic work budget (accepted steps); 0 = unlimited.  A cell that
                                    exhausts it stops like the reference's "Premature finish" */
+  double rt_cost_f, rt_cost_jac, rt_cost_lu; /* modelled seconds per chem_ode_f call, per full Jacobian (NEQ calls of
+                                   chem_ode_jac) and per factorisation incl. its solves; defaults 47e-6, 10.4e-3, 1.0e-3 =
+                                   the reference on one core of the build host */
 } racgpu_params;
 
-/* per-cell counters returned by racgpu_solve_batch (int64 x RACGPU_NSTAT per cell) */
-#define RACGPU_NSTAT 16
+/* per-cell counters returned by the solve calls (int64 x RACGPU_NSTAT per cell) */
+#define RACGPU_NSTAT 20
 enum { RACGPU_S_NST = 0, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_NERR, RACGPU_S_NREC_REAL,
        RACGPU_S_QSUM /* sum of the order used over accepted steps */, RACGPU_S_NCFAIL_ETFAIL,
        /* shader-clock cycles of the cell's wave, whole solve and per phase (f(y), Jacobian, LU, triangular solves) */
        RACGPU_S_CYC_TOTAL, RACGPU_S_CYC_RHS, RACGPU_S_CYC_JAC, RACGPU_S_CYC_LU, RACGPU_S_CYC_SOLVE,
        /* split of the LU cycles: column scatter, pivots applied through LDS, pivots of the dense trailing block */
-       RACGPU_S_CYC_LU_SCATTER, RACGPU_S_CYC_LU_LDS, RACGPU_S_CYC_LU_REG };
+       RACGPU_S_CYC_LU_SCATTER, RACGPU_S_CYC_LU_LDS, RACGPU_S_CYC_LU_REG,
+       RACGPU_S_ISAV,  /* index (1-based) of the record handed back: the last one whose T and H2 entries are not NaN
+                          (src/disk.f90:1716-1721); <= 1 means "No useful data produced": y and t_final were left alone */
+       RACGPU_S_NITER, /* local iterations used (racgpu_calc_cells; 1 for a plain solve) */
+       RACGPU_S_NREC,  /* n_record of this cell's (last) run, from its own t0, t_max and first step (src/chemistry.f90:1916-1938) */
+       RACGPU_S_SPARE };
+
+/* per-cell values the path writes back into the cell record (double x RACGPU_NOUT per cell) */
+#define RACGPU_NOUT 3
+enum { RACGPU_O_R_H2_FORM = 0,     /* chem_params%R_H2_form_rate_coeff [s^-1] (src/chemistry.f90:804,891); untouched if the network
+                                      has no H2-formation reaction */
+       RACGPU_O_N_MOL_ON_GRAIN,    /* chem_params%n_mol_on_grain: get_ice_coverage's side effect on the handed-back abundances
+                                      (src/chemistry.f90:989-1003, src/disk.f90:1736); untouched when isav <= 1 */
+       RACGPU_O_T_END };           /* touts(n_record_real): where the integration itself stopped (>= t_final when the tail of the
+                                      record held NaNs) */
+
+/* flags of racgpu_evol_solve_batch */
+#define RACGPU_F_RECTIFY 1 /* apply rectify_abundances (src/chemistry.f90:2170-2201) to y before integrating: the continue path */
 
 /* where the caller's cell/abundance/output buffers live */
 #define RACGPU_MEM_HOST 0
@@ -136,6 +158,29 @@ int racgpu_newton_solve(racgpu_network *, const racgpu_params *, const double *c
  */
 int racgpu_solve_batch(racgpu_network *, const racgpu_params *, int64_t ncell, const double *cells, double *y,
                        double *t_final, int32_t *quality, int64_t *stats, double *record, double *touts, int mem);
+/* The same with everything chem_evol_solve reads from chemsol_params per cell and per local iteration:
+ *   t0       [ncell]  chemsol_params%t0 (src/chemistry.f90:419); NULL = 0.  As in set_initial_condition_4solver_continue
+ *                     (src/disk.f90:2128-2130) the first output step of a cell is max(params.dt_first_step, 1e-3*t0), and
+ *                     n_record follows from (t_max - t0) and that step (chem_evol_solve_prepare_ongoing)
+ *   tol_j    [ncell]  int32: j of chem_set_solver_flags_alt(j) per cell; NULL = params.tol_policy_j for all
+ *   cell_out [ncell*RACGPU_NOUT] out (NULL ok): RACGPU_O_*
+ *   flags    RACGPU_F_*
+ * y/t_final out follow the caller's hand-off rule (src/disk.f90:1716-1733): the last record without NaN in T and H2, and its
+ * time; stats[RACGPU_S_ISAV] says which record that was. */
+int racgpu_evol_solve_batch(racgpu_network *, const racgpu_params *, int64_t ncell, const double *cells, double *y,
+                            const double *t0, const int32_t *tol_j, double *t_final, int32_t *quality, int64_t *stats,
+                            double *record, double *touts, double *cell_out, int flags, int mem);
+/* calc_this_cell's chemistry for a batch (src/disk.f90:1651-1791): up to nlocal_iter local iterations per cell.  Iteration 1
+ * integrates every cell from t = 0 with chem_set_solver_flags_alt(1).  A cell whose run ended with quality != 0 before half
+ * of its t_max goes into iteration j = 2, 3, ...: abundances of the hand-off record, rectify_abundances, t0 = t_final,
+ * first step max(dt0, 1e-3 t0), tolerances of policy j -- all cells of an iteration in ONE launch.  An iteration that does
+ * not get past the previous t_final ("Local iteration does not proceed") or produces no record without NaN ends the
+ * cell's loop as in the reference.  y in: abundances at t = 0 (racgpu_init_abundances); out: the handed-back abundances.
+ * stats: work counters summed over the iterations, RACGPU_S_NITER = iterations used.  params.tol_policy_j is ignored. */
+int racgpu_calc_cells(racgpu_network *, const racgpu_params *, int32_t nlocal_iter, int64_t ncell, const double *cells, double *y,
+                      double *t_final, int32_t *quality, int64_t *stats, double *cell_out, int mem);
+/* rectify_abundances (src/chemistry.f90:2170-2201) on host arrays: y[c, E-] += sum(charge * y[c, :]) */
+int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
 /* Scheduling hint for the following racgpu_solve_batch calls (an extension: the reference has no counterpart; its
  * cell loop, src/disk.f90:864-1010, takes cells in grid order).  cost[ncell] (host memory) is any per-cell measure
  * of expected work, e.g. the step count RACGPU_S_NST or the cycle count RACGPU_S_CYC_TOTAL the same cell needed in

@@ -20,8 +20,13 @@ from .cells import NPAR
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RACGPU_LIB") or os.path.join(_HERE, "libracgpu.so")  # RACGPU_LIB: developer builds
-NSTAT = 16
+NSTAT = 20
+NOUT = 3
 MEM_HOST, MEM_DEVICE = 0, 1
+F_RECTIFY = 1
+(S_NST, S_NFE, S_NJE, S_NLU, S_NERR, S_NREC_REAL, S_QSUM, S_NCFAIL_ETFAIL, S_CYC_TOTAL, S_CYC_RHS, S_CYC_JAC, S_CYC_LU,
+ S_CYC_SOLVE, S_CYC_LU_SCATTER, S_CYC_LU_LDS, S_CYC_LU_REG, S_ISAV, S_NITER, S_NREC, S_SPARE) = range(NSTAT)
+O_R_H2_FORM, O_N_MOL_ON_GRAIN, O_T_END = range(NOUT)
 
 # every extern "C" symbol include/racgpu.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
@@ -30,7 +35,8 @@ ABI_SYMBOLS = [
     "racgpu_species_attrs", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
-    "racgpu_solve_batch", "racgpu_set_cost_hints", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
+    "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_rectify_abundances",
+    "racgpu_set_cost_hints", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
 ]
 
 
@@ -44,6 +50,7 @@ class ChemsolParams(C.Structure):
         ("mxstep_per_interval", C.c_int32), ("steps_reset_solver", C.c_int32), ("H2_form_use_moeq", C.c_int32),
         ("evol_dust_size", C.c_int32), ("use_special_gH_mobi", C.c_int32), ("tol_policy_j", C.c_int32),
         ("max_steps_per_cell", C.c_int64),
+        ("rt_cost_f", C.c_double), ("rt_cost_jac", C.c_double), ("rt_cost_lu", C.c_double),
     ]
 
 
@@ -91,6 +98,9 @@ def lib():
     L.racgpu_jac_csc.argtypes = [vp, pp, dp, C.c_int64, dp, dp]
     L.racgpu_newton_solve.argtypes = [vp, pp, dp, C.c_int64, dp, C.c_double, dp]
     L.racgpu_solve_batch.argtypes = [vp, pp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.racgpu_evol_solve_batch.argtypes = [vp, pp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int]
+    L.racgpu_calc_cells.argtypes = [vp, pp, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.racgpu_rectify_abundances.argtypes = [vp, C.c_int64, dp]
     L.racgpu_workspace_bytes_per_cell.restype = C.c_int64
     L.racgpu_workspace_bytes_per_cell.argtypes = [vp]
     L.racgpu_set_cost_hints.restype = C.c_int
@@ -232,26 +242,55 @@ class Network:
         _check(lib().racgpu_newton_solve(self._h, C.byref(params), _dp(cr), cr.shape[0], _dp(y), gamma, _dp(x)))
         return x
 
-    def evol_solve_batch(self, params, cell_records, y, record=False):
-        """chem_cal_rates + chem_set_solver_flags_alt + chem_evol_solve for every cell (host arrays)."""
+    def evol_solve_batch(self, params, cell_records, y, record=False, t0=None, tol_j=None, rectify=False):
+        """chem_cal_rates + chem_set_solver_flags_alt + chem_evol_solve for every cell (host arrays).
+        t0 [ncell]: chemsol_params%t0 per cell (continue runs: first step max(dt0, 1e-3 t0)); tol_j [ncell]: policy j per cell;
+        rectify: apply rectify_abundances first (set_initial_condition_4solver_continue).  y/t_final out follow the
+        hand-off rule (last record without NaN), stats[:, S_ISAV] tells which record; cell_out = RACGPU_O_* values."""
         cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
         n = cr.shape[0]
         y = np.array(y, np.float64).reshape(n, self.nSpecies).copy()
-        tf = np.zeros(n); q = np.zeros(n, np.int32); st = np.zeros((n, NSTAT), np.int64)
+        tf = np.zeros(n); q = np.zeros(n, np.int32); st = np.zeros((n, NSTAT), np.int64); co = np.full((n, NOUT), np.nan)
+        t0a = None if t0 is None else np.ascontiguousarray(np.broadcast_to(np.asarray(t0, np.float64), (n,)))
+        tja = None if tol_j is None else np.ascontiguousarray(np.broadcast_to(np.asarray(tol_j, np.int32), (n,)))
         rec = tos = None
         if record:
             nrec = lib().racgpu_n_record(C.byref(params), 0.0, params.t_max)
             rec = np.zeros((n, nrec, self.nSpecies + 1)); tos = np.zeros((n, nrec))
-        _check(lib().racgpu_solve_batch(self._h, C.byref(params), n, cr.ctypes.data, y.ctypes.data, tf.ctypes.data,
-                                        q.ctypes.data, st.ctypes.data, rec.ctypes.data if record else None,
-                                        tos.ctypes.data if record else None, MEM_HOST))
-        return dict(y=y, t_final=tf, quality=q, stats=st, record=rec, touts=tos,
+        _check(lib().racgpu_evol_solve_batch(self._h, C.byref(params), n, cr.ctypes.data, y.ctypes.data,
+                                             None if t0a is None else t0a.ctypes.data, None if tja is None else tja.ctypes.data,
+                                             tf.ctypes.data, q.ctypes.data, st.ctypes.data, rec.ctypes.data if record else None,
+                                             tos.ctypes.data if record else None, co.ctypes.data, F_RECTIFY if rectify else 0, MEM_HOST))
+        return dict(y=y, t_final=tf, quality=q, stats=st, record=rec, touts=tos, cell_out=co,
                     kernel_ms=lib().racgpu_last_kernel_ms(self._h))
 
-    def evol_solve_batch_device(self, params, ncell, cells_ptr, y_ptr, t_final_ptr=None, quality_ptr=None, stats_ptr=None):
+    def calc_cells(self, params, cell_records, y, nlocal_iter=4):
+        """calc_this_cell's chemistry for every cell (reference src/disk.f90:1651-1791): up to nlocal_iter local iterations,
+        each iteration one batched launch over the cells that still need it (host arrays)."""
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        n = cr.shape[0]
+        y = np.array(y, np.float64).reshape(n, self.nSpecies).copy()
+        tf = np.zeros(n); q = np.zeros(n, np.int32); st = np.zeros((n, NSTAT), np.int64); co = np.full((n, NOUT), np.nan)
+        _check(lib().racgpu_calc_cells(self._h, C.byref(params), nlocal_iter, n, cr.ctypes.data, y.ctypes.data, tf.ctypes.data,
+                                       q.ctypes.data, st.ctypes.data, co.ctypes.data, MEM_HOST))
+        return dict(y=y, t_final=tf, quality=q, stats=st, cell_out=co, kernel_ms=lib().racgpu_last_kernel_ms(self._h))
+
+    def rectify_abundances(self, y):
+        y = np.array(y, np.float64).reshape(-1, self.nSpecies).copy()
+        _check(lib().racgpu_rectify_abundances(self._h, y.shape[0], _dp(y)))
+        return y
+
+    def evol_solve_batch_device(self, params, ncell, cells_ptr, y_ptr, t_final_ptr=None, quality_ptr=None, stats_ptr=None,
+                                t0_ptr=None, tol_j_ptr=None, cell_out_ptr=None, flags=0):
         """Same, on device pointers (e.g. torch tensors' data_ptr()); asynchronous on the handle's stream."""
-        _check(lib().racgpu_solve_batch(self._h, C.byref(params), ncell, cells_ptr, y_ptr, t_final_ptr, quality_ptr,
-                                        stats_ptr, None, None, MEM_DEVICE))
+        _check(lib().racgpu_evol_solve_batch(self._h, C.byref(params), ncell, cells_ptr, y_ptr, t0_ptr, tol_j_ptr, t_final_ptr,
+                                             quality_ptr, stats_ptr, None, None, cell_out_ptr, flags, MEM_DEVICE))
+
+    def calc_cells_device(self, params, nlocal_iter, ncell, cells_ptr, y_ptr, t_final_ptr=None, quality_ptr=None, stats_ptr=None,
+                          cell_out_ptr=None):
+        """racgpu_calc_cells on device pointers (synchronises the handle's stream between local iterations)."""
+        _check(lib().racgpu_calc_cells(self._h, C.byref(params), nlocal_iter, ncell, cells_ptr, y_ptr, t_final_ptr, quality_ptr,
+                                       stats_ptr, cell_out_ptr, MEM_DEVICE))
 
     def set_cost_hints(self, cost=None):
         """Per-cell expected work (e.g. stats[:, S_NST] of the previous global iteration) for the following

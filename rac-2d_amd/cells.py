@@ -56,3 +56,111 @@ def tmax_this(omega_kepler, t_max0=1e6, n_orbit_tmax=1e5, use_fixed_tmax=False):
     seconds_per_year = 3600.0 * 24.0 * 365.0
     two_pi = 6.283185307179586476925
     return np.minimum(float(t_max0), np.maximum(1e2, n_orbit_tmax * two_pi / omega / seconds_per_year))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs[2]/[3]: a synthetic Andrews-2009-like (r, z) grid
+# ---------------------------------------------------------------------------------------------------------
+MSUN_CGS = 1.9891e33          # reference src/sub_global_variables.f90:38
+AU_CM = 1.49597871e13         # :55
+G_CGS = 6.67428e-8            # :27
+SEC_PER_YEAR = 3600.0 * 24.0 * 365.0
+
+
+def andrews_density(r_au, z_au, Md=2e-2, rin=0.1, rout=200.0, rc=80.0, hc=10.0, gam=1.5, psi=1.0,
+                    r0_in_exp=3.5, rs_in_exp=1e2, p_in_exp=1.0, f_in_exp=1e-5, particlemass=1.4 * MP_CGS):
+    """n_H [cm^-3] of the reference's analytic gas disk, reference src/grid.f90:1741-1818 (Andrews_dens) with the
+    README's `a_disk%andrews_gas` values (README.md:225-235): Md 0.02 Msun, rc 80 AU, hc 10 AU, gamma 1.5, psi 1,
+    inner taper below 3.5 AU (factor 1e-5), no outer taper, no flattening."""
+    r = np.asarray(r_au, dtype=np.float64)
+    z = np.asarray(z_au, dtype=np.float64)
+    sigma_c = (2.0 - gam) * Md / (2.0 * math.pi * rc ** 2) / (math.exp(-(rin / rc) ** (2.0 - gam)) - math.exp(-(rout / rc) ** (2.0 - gam)))
+    rrc = r / rc
+    taper = np.where(r < r0_in_exp, np.exp(-((r0_in_exp - r) / rs_in_exp) ** p_in_exp) * f_in_exp, 1.0)
+    sigma = sigma_c * rrc ** (-gam) * np.exp(-rrc ** (2.0 - gam)) * taper  # Msun / AU^2
+    h = hc * rrc ** psi
+    n = sigma / (math.sqrt(2.0 * math.pi) * h) * np.exp(-0.5 * (z / h) ** 2) * MSUN_CGS / (AU_CM ** 3 * particlemass)
+    return np.where((r < rin) | (r > rout), 0.0, n), h
+
+
+def andrews_grid(ncol=200, nz=100, rmin=0.1, rmax=200.0, zr_max=0.6, star_mass_msun=0.6, t_max0=1e6,
+                 n_orbit_tmax=1e5, use_fixed_tmax=False, a_cm=1e-5, return_geometry=False):
+    """BASELINE configs[2]: ~20 k frozen cell records of a full 2-D disk grid.
+
+    The real grid needs the reference's Monte-Carlo radiative transfer (out of scope), so every field below is a
+    STATED CLOSED FORM of the analytic Andrews gas disk -- a workload with the reference grid's structure
+    (columns inner -> outer, cells top -> bottom as the sweep visits them, src/disk.f90:885-937, 2512-2520) and its
+    dynamic range (n_H 1e3...1e14, Av 1e-4...1e5, t_max by the orbit rule), not a physical model:
+
+      geometry   ncol columns log-spaced in r in [rmin, rmax] AU; nz cells per column at z/r = (k+1/2)/nz * zr_max,
+                 ordered top -> bottom within a column, columns inner -> outer
+      n_gas      andrews_density(r, z), floored at 1e2 cm^-3
+      columns    N_toISM(r,z) = int_z^inf n dz' (vertical, analytic erfc); N_toStar(r,z) = int along the ray from the star
+                 at constant z/r (h ~ r for psi = 1, so the Gaussian factor is constant along the ray)
+      Av         N * 5.3e-22 (both directions; the reference's calc_Av_*_from_Ncol conversion)
+      UV         G0_UV_toISM = 1; G0_UV_toStar = 1e3 (100 AU / d)^2, d^2 = r^2 + z^2; G0_UV_H2phd =
+                 G0_UV_toStar_photoDesorb = G0_UV_toStar e^{-2.6 Av_toStar}; phflux_Lya = 1e7 G0_UV_toStar/1e3 e^{-2.6 Av_toStar}
+      ionisation zeta_CR = 1.36e-17; zeta_Xray = 1e-13 (1 AU / d)^2 e^{-N_toStar / 1e24}
+      dust       0.1 um grains, dust/gas mass ratio 0.01 (make_cell), albedo 0.5
+      Tdust      T_mid = 120 K (r / 1 AU)^-0.5 (floor 8 K) in the shadow, T_thin = 280 K (d / 1 AU)^-0.5 unshadowed:
+                 Tdust = T_mid + (T_thin - T_mid) e^{-Av_toStar}, clipped to [5, 1500] K
+      Tgas       Tdust (1 + 9 e^{-2.6 Av_toStar} / (1 + n_gas / 1e7)), clipped to <= 5000 K (hot, thin, irradiated surface)
+      shielding  f_H2 = Draine-Bertoldi 1996 eq. 37 (reference src/disk.f90:1887-1897, b5 = 1) of N_H2 = 0.1 N;
+                 f_CO = min(1, (1e-5 N / 1e15)^-0.75); f_H2O = min(1, (1e-6 N / 1e17)^-0.5);
+                 f_OH = min(1, (1e-7 N / 1e17)^-0.5), N the column in the respective direction
+      t_max      tmax_this(omega_Kepler) (orbit rule, src/disk.f90:2078-2085) unless use_fixed_tmax
+    """
+    r = rmin * (rmax / rmin) ** ((np.arange(ncol) + 0.5) / ncol)            # column centres
+    mu = zr_max * (nz - 0.5 - np.arange(nz)) / nz                            # z/r, top -> bottom
+    R, MU = np.meshgrid(r, mu, indexing="ij")                                 # [ncol, nz]
+    Z = R * MU
+    n, H = andrews_density(R, Z)
+    n_mid, _ = andrews_density(r, 0.0 * r)
+    n = np.maximum(n, 1e2)
+    from math import erfc
+    erfc_v = np.vectorize(erfc)
+    N_ism = n_mid[:, None] * H * AU_CM * math.sqrt(math.pi / 2.0) * erfc_v(Z / (math.sqrt(2.0) * H))
+    # towards the star: int_{rin}^{r} n_mid(r') dr' * sqrt(1 + mu^2) * exp(-(mu r'/h(r'))^2 / 2), the last factor constant for psi = 1
+    edges = rmin * (rmax / rmin) ** (np.arange(ncol + 1) / ncol)
+    cum = np.concatenate([[0.0], np.cumsum(n_mid * np.diff(edges))]) * AU_CM   # up to the outer edge of each column
+    N_in = 0.5 * (cum[:-1] + cum[1:])                                           # up to the column centre
+    gauss = np.exp(-0.5 * (MU * (80.0 / 10.0)) ** 2)
+    N_star = N_in[:, None] * np.sqrt(1.0 + MU ** 2) * gauss
+    Av_ism, Av_star = N_ism * 5.3e-22, N_star * 5.3e-22
+    d2 = R * R + Z * Z
+    g0 = 1e3 * (100.0 ** 2) / d2
+    att = g0 * np.exp(-np.minimum(2.6 * Av_star, 700.0))
+    lya = 1e7 * att / 1e3
+    zx = 1e-13 / d2 * np.exp(-np.minimum(N_star / 1e24, 700.0))
+    t_mid = np.maximum(120.0 * R ** -0.5, 8.0)
+    t_thin = 280.0 * d2 ** -0.25
+    tdust = np.clip(t_mid + (t_thin - t_mid) * np.exp(-np.minimum(Av_star, 700.0)), 5.0, 1500.0)
+    tgas = np.minimum(tdust * (1.0 + 9.0 * np.exp(-np.minimum(2.6 * Av_star, 700.0)) / (1.0 + n / 1e7)), 5000.0)
+
+    def f_h2(N):
+        x = 0.1 * N / 5e14
+        s = np.sqrt(1.0 + x)
+        return 0.965 / (1.0 + x) ** 2 + 0.035 / s * np.exp(-8.5e-4 * s)
+
+    def f_pow(N, x_mol, n0, p):
+        return np.minimum(1.0, np.maximum(x_mol * N / n0, 1e-300) ** (-p))
+
+    sig = math.pi * a_cm * a_cm
+    d2h = 0.01 * 1.4 * MP_CGS / (4.0 * math.pi / 3.0 * a_cm ** 3 * 2.0)
+    omega = np.sqrt(G_CGS * star_mass_msun * MSUN_CGS / (R * AU_CM) ** 3)
+    tmax = tmax_this(omega, t_max0, n_orbit_tmax, use_fixed_tmax)
+    out = np.empty((ncol, nz, NPAR))
+    out[..., P_TGAS] = tgas; out[..., P_TDUST] = tdust; out[..., P_NGAS] = n; out[..., P_GRAIN_RADIUS] = a_cm
+    out[..., P_SIGDUST] = sig; out[..., P_NDUST] = n * d2h; out[..., P_D2H] = d2h; out[..., P_SITES] = 4.0 * sig * 1e15
+    out[..., P_ALBEDO] = 0.5; out[..., P_ZETA_CR] = 1.36e-17; out[..., P_ZETA_X] = zx; out[..., P_NCOL_ISM] = N_ism
+    out[..., P_AV_ISM] = Av_ism; out[..., P_AV_STAR] = Av_star; out[..., P_G0_ISM] = 1.0; out[..., P_G0_STAR] = g0
+    out[..., P_G0_H2PHD] = att; out[..., P_G0_PHOTODES] = att; out[..., P_LYA] = lya
+    out[..., P_FSS_ISM_H2] = f_h2(N_ism); out[..., P_FSS_ISM_CO] = f_pow(N_ism, 1e-5, 1e15, 0.75)
+    out[..., P_FSS_ISM_H2O] = f_pow(N_ism, 1e-6, 1e17, 0.5); out[..., P_FSS_ISM_OH] = f_pow(N_ism, 1e-7, 1e17, 0.5)
+    out[..., P_FSS_STAR_H2] = f_h2(N_star); out[..., P_FSS_STAR_CO] = f_pow(N_star, 1e-5, 1e15, 0.75)
+    out[..., P_FSS_STAR_H2O] = f_pow(N_star, 1e-6, 1e17, 0.5); out[..., P_FSS_STAR_OH] = f_pow(N_star, 1e-7, 1e17, 0.5)
+    out[..., P_TMAX] = tmax
+    cells = np.ascontiguousarray(out.reshape(ncol * nz, NPAR))
+    if return_geometry:
+        return cells, np.ascontiguousarray(R.reshape(-1)), np.ascontiguousarray(Z.reshape(-1))
+    return cells

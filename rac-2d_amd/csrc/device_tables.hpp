@@ -37,21 +37,14 @@ struct DevNet {
   // w0: kind | n_reac<<8 | a<<16 | b<<32 ; w1: targets 0..3 ; w2: targets 4..6 (u16 each, 0xFFFF = none);
   // target slots 0..n_reac-1 subtract, the rest add
   const uint64_t *rhs_w0, *rhs_w1, *rhs_w2;
-  // ---- Jacobian gather ----
-  const int *jac_order;      // entries sorted by decreasing term count, padded to a multiple of 64 with -1
-  int jac_slots;
-  const int *term_ptr;       // [nnzJ+1]
-  const uint64_t *terms;     // rxn | sa<<16 | kind<<32 | flags<<40 | sb<<48
-  const uint8_t *jac_isdiag; // [nnzJ]
-  // the same gather as one linear stream (built in engine.hip, upload): jac_rows rows of 64 term words
+  // ---- Jacobian gather: one linear stream (built in engine.hip, upload) of jac_rows rows of 64 term words
+  // (rxn | sa<<16 | kind<<32 | flags<<40 | sb<<48), entries sorted by decreasing term count, 64 per pass
   const uint64_t *jac_stream, *jac_slot;
   const uint32_t *jac_rowflag;
   int jac_rows;
   // ---- sparse LU of the permuted species block ----
   const uint16_t *perm;      // perm[new] = old
-  const int *Lcolptr, *Lcolend, *Ucolptr, *Ucolend, *Udptr, *Pcolptr; // storage layout: see network.hpp, struct Symbolic
-  const uint16_t *Lrow, *Urow, *Prow;
-  const int *Ppos;            // CSC entry -> position in the permuted-column storage of P
+  const uint16_t *Lrow, *Urow, *Prow; // storage layout: see network.hpp, struct Symbolic
   const uint8_t *Pdiag;       // [nnzJ] in storage order: 1 on the diagonal
   // triangular-solve schedules: one packed word per stored entry of the streamed part, row | col<<10 |
   // (next chunk continues this level)<<20; chunks of 64 entries hold one dependency level each; null: row == col
@@ -68,7 +61,10 @@ struct DevNet {
   int nzl_stream, nzu_stream; // entries of the streamed parts; the trailing columns follow back to back (closed-form starts)
   // type-11 special indices (0-based, -1 none)
   int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;
+  int i_H2;                  // hand-off test (reference src/disk.f90:1716-1721)
+  int r_h2form;              // last reaction whose coefficient the reference copies into R_H2_form_rate_coeff (-1 none)
   const uint8_t *s_tolclass; // 0 generic, 1 one of the ten special species, 2 Grain0/+/-, 3 surface species (applied in that order)
+  const int8_t *s_charge;    // elements(1, :) of every species (rectify_abundances, reference src/chemistry.f90:2170-2201)
 };
 
 struct DevParams {
@@ -76,6 +72,7 @@ struct DevParams {
   int mxstep, steps_reset, use_special_gH_mobi, tol_j;
   long long max_steps_per_cell;
   double max_runtime_allowed; // seconds of MODELLED reference CPU time (<= 0: guards off)
+  double rt_cost_f, rt_cost_jac, rt_cost_lu; // modelled seconds per f evaluation / Jacobian / factorisation (racgpu_params)
   int n_record; // for params.t_max (record layout)
   int debug_max_calls; // developer aid (env RACGPU_DEBUG_TRACE): stop a cell after this many step calls; 0 = off
   double elco[6][7];  // BDF coefficients el(i), i = 1..nq+1, per order nq = 1..5 (DCFODE, reference src/opkda1.f:146-171)
@@ -90,6 +87,7 @@ struct DevWork { // per-cell workspace, all f64, cell-major
   double *U;       // [ncell][nzu]
   double *Dinv;    // [ncell][npad]
   double *rtol, *atol; // [ncell][npad]
+  double *ygood;   // [ncell][npad] the last record whose T and H2 entries are not NaN (the hand-off record)
   int *counter;    // work queue head
   double *trace;   // developer aid: [debug_max_calls][8] step log of cell 0, or null
   int *marker;     // developer aid: host-mapped progress word (null when off)

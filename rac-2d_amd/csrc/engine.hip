@@ -35,10 +35,12 @@ static int fail(const std::string &m) { g_err = m; return -1; }
 struct LdsViews { double *y, *savf, *acor, *ewt, *wx; };
 __device__ __forceinline__ LdsViews carve(double *lds, int nlds) { return {lds, lds + nlds, lds + 2 * nlds, lds + 3 * nlds, lds + 4 * nlds}; }
 
-__global__ __launch_bounds__(64) void k_rates(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, const double *cells, double *rates_out) {
+__global__ __launch_bounds__(64) void k_rates(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, const double *cells, double *rates_out,
+                                              double *cell_out) {
   const DevNet &N = *Np; const DevParams &P = *Pp;
   const int cell = blockIdx.x, lane = threadIdx.x;
-  dev_rates(N, P, cells + (size_t)cell * RACGPU_NPAR, rates_out + (size_t)cell * N.nR, lane);
+  dev_rates(N, P, cells + (size_t)cell * RACGPU_NPAR, rates_out + (size_t)cell * N.nR, lane,
+            cell_out ? cell_out + (size_t)cell * RACGPU_NOUT + RACGPU_O_R_H2_FORM : nullptr);
 }
 
 __global__ __launch_bounds__(64) void k_rhs(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, const double *cells, const double *yin, double *rates_ws, double *ydot_out) {
@@ -101,10 +103,17 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
 
 // The hot path.  Persistent: each wave pulls cells from a queue until it is empty; its workspace is per wave
 // (slot), not per cell, so the HBM footprint is nslots * ~0.4 MB whatever the batch size.
-__global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, int ncell, const double *__restrict__ cells,
-                                              double *__restrict__ yio, double *__restrict__ t_final, int *__restrict__ quality,
-                                              long long *__restrict__ stats, double *__restrict__ record, double *__restrict__ touts,
-                                              const int *__restrict__ order) {
+struct SolveArgs {
+  int ncell, flags;                 // flags: RACGPU_F_*
+  const double *cells;              // [ncell][NPAR]
+  double *yio;                      // [ncell][nS]
+  const double *t0;                 // [ncell] or null (0)
+  const int *tolj;                  // [ncell] or null (DevParams::tol_j)
+  double *t_final; int *quality; long long *stats; double *record, *touts, *cell_out;
+  const int *order;                 // queue order or null
+};
+
+__global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
   extern __shared__ double lds[];
   const DevNet &N = *Np; const DevParams &P = *Pp;
   const int lane = threadIdx.x, slot = blockIdx.x, n = N.nS, nlds = (n + 1) & ~1;
@@ -114,51 +123,126 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
   c.rates = nullptr; c.yh = W.yh + (size_t)slot * 6 * N.npad; c.Pv = W.P + (size_t)slot * N.nnzJ;
   c.Lv = W.L + (size_t)slot * N.nzl; c.Uv = W.U + (size_t)slot * N.nzu; c.Dinv = W.Dinv + (size_t)slot * N.npad;
   c.rtol = W.rtol + (size_t)slot * N.npad; c.atol = W.atol + (size_t)slot * N.npad;
-  c.lane = lane; c.n = n; c.npad = N.npad; c.inv_neq = 1.0 / (double)(n + 1);
+  double *ygood = W.ygood + (size_t)slot * N.npad;
+  c.lane = lane; c.n = n; c.npad = N.npad;
   c.marker = slot == 0 ? W.marker : nullptr;
+  g_wc.inv_neq = 1.0 / (double)(n + 1);
   for (;;) {
     int cell = 0;
     if (lane == 0) cell = atomicAdd(W.counter, 1);
     cell = uniform_i(cell);
     dev_mark(c, 10 + cell);
-    if (cell >= ncell) break;
-    if (order) cell = order[cell]; // longest-expected-first schedule (racgpu_set_cost_hints)
-    const double *cp = cells + (size_t)cell * RACGPU_NPAR;
+    if (cell >= A.ncell) break;
+    if (A.order) cell = A.order[cell]; // longest-expected-first schedule (racgpu_set_cost_hints)
+    const double *cp = A.cells + (size_t)cell * RACGPU_NPAR;
     const long long cyc0 = dev_clock();
-    c.cyc_rhs = c.cyc_jac = c.cyc_lu = c.cyc_solve = 0;
-    c.cyc_lu_part[0] = c.cyc_lu_part[1] = c.cyc_lu_part[2] = 0; c.cyc_lu_part[3] = 0;
-    c.Tgas = cp[RACGPU_P_TGAS]; c.nsite = cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES];
+    for (int k = 0; k < 8; ++k) g_wc.cyc[k] = 0;
+    g_wc.Tgas = cp[RACGPU_P_TGAS]; g_wc.nsite = cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES];
+    // The caller's per-cell time window (set_initial_condition_4solver / _continue, reference src/disk.f90:2075-2097,
+    // 2128-2144): t_max of the cell, start time t0, first output step max(dt0, 1e-3 t0), and n_record recomputed from
+    // them by chem_evol_solve_prepare_ongoing (src/chemistry.f90:1916-1938) for every cell and every local iteration.
     const double t_max = cp[RACGPU_P_TMAX] > 0.0 ? cp[RACGPU_P_TMAX] : P.t_max;
-    const int n_record = (int)ceil(log((t_max - 0.0) / P.dt_first_step * (P.ratio_tstep - 1.0) + 1.0) / log(P.ratio_tstep)) + 1;
+    const double t0 = A.t0 ? A.t0[cell] : 0.0;
+    const double dt_first = fmax(P.dt_first_step, t0 * 1e-3);
+    const bool runnable = t_max > t0;
+    const int n_record = runnable ? (int)ceil(log((t_max - t0) / dt_first * (P.ratio_tstep - 1.0) + 1.0) / log(P.ratio_tstep)) + 1 : 1;
     dev_mark(c, 1);
-    dev_tolerances(N, P, cp[RACGPU_P_D2H], c.rtol, c.atol, c.rT, c.aT, lane);
+    { double rT, aT; dev_tolerances(N, P, A.tolj ? A.tolj[cell] : P.tol_j, cp[RACGPU_P_D2H], c.rtol, c.atol, rT, aT, lane); g_wc.rT = rT; g_wc.aT = aT; }
     dev_mark(c, 2);
     c.rates = W.rates + (size_t)cell * N.nR; // filled by k_rates for the whole batch just before this launch
     dev_mark(c, 3);
-    for (int i = lane; i < n; i += 64) c.y[i] = yio[(size_t)cell * n + i];
+    for (int i = lane; i < n; i += 64) c.y[i] = A.yio[(size_t)cell * n + i];
     wave_sync();
-    double *rec = record ? record + (size_t)cell * P.n_record * (n + 1) : nullptr;
-    double *tos = touts ? touts + (size_t)cell * P.n_record : nullptr;
-    const int nrec = record || touts ? min(n_record, P.n_record) : n_record;
-    CellResult R = dev_evol_solve(N, P, c, t_max, nrec, rec, tos, cell == 0 ? W.trace : nullptr);
+    if (A.flags & RACGPU_F_RECTIFY) { // rectify_abundances (src/chemistry.f90:2170-2201): E- takes up the net charge
+      double q = 0.0;
+      for (int i = lane; i < n; i += 64) q += c.y[i] * (double)gptr(N.s_charge)[i];
+      q = wave_sum(q);
+      if (lane == 0 && N.i_E >= 0) c.y[N.i_E] = c.y[N.i_E] + q;
+      wave_sync();
+    }
+    double *rec = A.record ? A.record + (size_t)cell * P.n_record * (n + 1) : nullptr;
+    double *tos = A.touts ? A.touts + (size_t)cell * P.n_record : nullptr;
+    const int nrec = A.record || A.touts ? min(n_record, P.n_record) : n_record;
+    CellResult R = dev_evol_solve(N, P, c, t0, t_max, dt_first, nrec, rec, tos, ygood, cell == 0 ? W.trace : nullptr);
     dev_mark(c, 4);
     wave_sync();
-    for (int i = lane; i < n; i += 64) yio[(size_t)cell * n + i] = c.y[i];
+    // hand-off (src/disk.f90:1716-1733): record(:, isav), touts(isav); with isav <= 1 ("No useful data produced") the
+    // caller's abundances and t_final stay as they were
+    const bool useful = R.isav > 1;
+    double nmol = 0.0;
+    if (useful) {
+      for (int i = lane; i < n; i += 64) {
+        const double yi = ygood[i];
+        A.yio[(size_t)cell * n + i] = yi;
+        if (gptr(N.s_tolclass)[i] == 3) nmol += yi; // get_ice_coverage's side effect (src/chemistry.f90:989-1003)
+      }
+      nmol = wave_sum(nmol) / cp[RACGPU_P_D2H];
+    }
     if (lane == 0) {
-      if (t_final) t_final[cell] = R.t_final;
-      if (quality) quality[cell] = R.quality;
-      if (stats) {
-        long long *s = stats + (size_t)cell * RACGPU_NSTAT;
+      if (A.t_final) A.t_final[cell] = useful ? R.t_good : t0;
+      if (A.quality) A.quality[cell] = R.quality;
+      if (A.cell_out) {
+        double *o = A.cell_out + (size_t)cell * RACGPU_NOUT;
+        if (useful) o[RACGPU_O_N_MOL_ON_GRAIN] = nmol;
+        o[RACGPU_O_T_END] = R.t_final;
+      }
+      if (A.stats) {
+        long long *s = A.stats + (size_t)cell * RACGPU_NSTAT;
         s[RACGPU_S_NST] = R.nst; s[RACGPU_S_NFE] = R.nfe; s[RACGPU_S_NJE] = R.nje; s[RACGPU_S_NLU] = R.nlu;
         s[RACGPU_S_NERR] = R.nerr; s[RACGPU_S_NREC_REAL] = R.nrec_real; s[RACGPU_S_QSUM] = R.qsum; s[RACGPU_S_NCFAIL_ETFAIL] = R.nfail;
-        s[RACGPU_S_CYC_TOTAL] = dev_clock() - cyc0; s[RACGPU_S_CYC_RHS] = c.cyc_rhs; s[RACGPU_S_CYC_JAC] = c.cyc_jac;
-        s[RACGPU_S_CYC_LU] = c.cyc_lu; s[RACGPU_S_CYC_SOLVE] = c.cyc_solve;
-        s[13] = c.cyc_lu_part[0]; s[14] = c.cyc_lu_part[1]; s[15] = c.cyc_lu_part[2]; // finish = LU - the three
+        s[RACGPU_S_CYC_TOTAL] = dev_clock() - cyc0; s[RACGPU_S_CYC_RHS] = g_wc.cyc[CYC_RHS]; s[RACGPU_S_CYC_JAC] = g_wc.cyc[CYC_JAC];
+        s[RACGPU_S_CYC_LU] = g_wc.cyc[CYC_LU]; s[RACGPU_S_CYC_SOLVE] = g_wc.cyc[CYC_SOLVE];
+        s[13] = g_wc.cyc[CYC_LU_PART]; s[14] = g_wc.cyc[CYC_LU_PART + 1]; s[15] = g_wc.cyc[CYC_LU_PART + 2]; // finish = LU - the three
+        s[RACGPU_S_ISAV] = R.isav; s[RACGPU_S_NITER] = 1; s[RACGPU_S_NREC] = nrec; s[19] = 0;
       }
     }
     dev_mark(c, 6);
   }
   dev_mark(c, 7);
+}
+
+// ---- the caller's retry loop over local iterations (calc_this_cell, reference src/disk.f90:1651-1791), batched -----
+// gather the cells that go into local iteration j: compact copies of their records, abundances and start times
+__global__ void k_gather_pass(int nsel, const int *__restrict__ sel, int nS, const double *__restrict__ cells, const double *__restrict__ y,
+                              const double *__restrict__ t_final, double *__restrict__ cells_c, double *__restrict__ y_c, double *__restrict__ t0_c) {
+  const int f = blockIdx.x, cell = sel[f];
+  for (int i = threadIdx.x; i < RACGPU_NPAR; i += blockDim.x) cells_c[(size_t)f * RACGPU_NPAR + i] = cells[(size_t)cell * RACGPU_NPAR + i];
+  for (int i = threadIdx.x; i < nS; i += blockDim.x) y_c[(size_t)f * nS + i] = y[(size_t)cell * nS + i];
+  if (threadIdx.x == 0) t0_c[f] = t_final[cell];
+}
+
+// merge what local iteration j > 1 produced for the selected cells, in the order calc_this_cell applies it:
+//   touts(n_record_real) <= t_final of the previous iteration -> "does not proceed": nothing is taken over;
+//   quality is taken over; isav <= 1 -> "No useful data": abundances and t_final stay; else both are taken over.
+// The work counters add up over the iterations; NERR, n_record_real, isav, n_record are the last iteration's.
+__global__ void k_merge_pass(int nsel, const int *__restrict__ sel, int nS, int j, const double *__restrict__ y_c, const double *__restrict__ t_final_c,
+                             const int *__restrict__ quality_c, const long long *__restrict__ stats_c, const double *__restrict__ out_c,
+                             double *__restrict__ y, double *__restrict__ t_final, int *__restrict__ quality, long long *__restrict__ stats,
+                             double *__restrict__ cell_out) {
+  const int f = blockIdx.x, cell = sel[f];
+  const long long *sc = stats_c + (size_t)f * RACGPU_NSTAT;
+  long long *s = stats + (size_t)cell * RACGPU_NSTAT;
+  const bool proceeds = out_c[(size_t)f * RACGPU_NOUT + RACGPU_O_T_END] > t_final[cell];
+  const bool useful = sc[RACGPU_S_ISAV] > 1;
+  __syncthreads(); // every thread has read t_final[cell] before thread 0 may overwrite it
+  if (threadIdx.x == 0) {
+    static const int kAdd[] = {RACGPU_S_NST, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_QSUM, RACGPU_S_NCFAIL_ETFAIL, RACGPU_S_CYC_TOTAL,
+                               RACGPU_S_CYC_RHS, RACGPU_S_CYC_JAC, RACGPU_S_CYC_LU, RACGPU_S_CYC_SOLVE, 13, 14, 15};
+    for (int k : kAdd) s[k] += sc[k];
+    s[RACGPU_S_NITER] = j;
+    s[RACGPU_S_NERR] = sc[RACGPU_S_NERR]; s[RACGPU_S_NREC_REAL] = sc[RACGPU_S_NREC_REAL]; s[RACGPU_S_ISAV] = sc[RACGPU_S_ISAV];
+    s[RACGPU_S_NREC] = sc[RACGPU_S_NREC];
+    if (cell_out) cell_out[(size_t)cell * RACGPU_NOUT + RACGPU_O_T_END] = out_c[(size_t)f * RACGPU_NOUT + RACGPU_O_T_END];
+    if (proceeds) {
+      quality[cell] = quality_c[f];
+      if (useful) {
+        t_final[cell] = t_final_c[f];
+        if (cell_out) cell_out[(size_t)cell * RACGPU_NOUT + RACGPU_O_N_MOL_ON_GRAIN] = out_c[(size_t)f * RACGPU_NOUT + RACGPU_O_N_MOL_ON_GRAIN];
+      }
+    }
+  }
+  if (proceeds && useful)
+    for (int i = threadIdx.x; i < nS; i += blockDim.x) y[(size_t)cell * nS + i] = y_c[(size_t)f * nS + i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -274,19 +358,14 @@ void racgpu_network::upload() {
       return h.term_ptr[a + 1] - h.term_ptr[a] > h.term_ptr[b + 1] - h.term_ptr[b];
     });
     order.resize((size_t)(nnz + 63) / 64 * 64, -1);
-    dn.jac_slots = (int)order.size();
-    dn.jac_order = up(order);
-    dn.term_ptr = up(h.term_ptr);
     std::vector<uint64_t> tw(h.terms.size());
     for (size_t t = 0; t < tw.size(); ++t) {
       const JacTerm &x = h.terms[t];
       tw[t] = (uint64_t)x.rxn | ((uint64_t)x.other << 16) | ((uint64_t)x.kind << 32) | ((uint64_t)x.flags << 40) | ((uint64_t)x.other2 << 48);
     }
-    dn.terms = up(tw);
     std::vector<uint8_t> isd(nnz, 0);
     for (int j = 0; j < nS; ++j)
       for (int q = h.Jcolptr[j]; q < h.Jcolptr[j + 1]; ++q) if (h.Jrow[q] == j) isd[q] = 1;
-    dn.jac_isdiag = up(isd);
     // Term stream for the Jacobian gather: pass p handles the 64 entries order[64p .. 64p+63], one per lane; row i of
     // the pass holds term i of every lane's entry (null where an entry has fewer terms), so the kernel reads the terms
     // as one linear, coalesced, prefetchable stream.  rowflag marks the last row of every pass; slot words say where
@@ -326,12 +405,11 @@ void racgpu_network::upload() {
     Lrow.resize(Lrow.size() + 64, 0); Urow.resize(Urow.size() + 64, 0); // the LU prefetch reads up to 64 entries past a column
     Prow.resize(Prow.size() + 64, 0);
     dn.perm = up(perm); dn.Lrow = up(Lrow); dn.Urow = up(Urow); dn.Prow = up(Prow);
-    dn.Lcolptr = up(S.Lcolptr); dn.Lcolend = up(S.Lcolend); dn.Ucolptr = up(S.Ucolptr); dn.Ucolend = up(S.Ucolend); dn.Udptr = up(S.Udptr);
-    dn.Pcolptr = up(S.Pcolptr); dn.Ppos = up(S.Ppos);
     {
       std::vector<uint8_t> pd(S.Psrc.size(), 0);
       for (int j = 0; j < nS; ++j)
         for (int q = h.Jcolptr[j]; q < h.Jcolptr[j + 1]; ++q) if (h.Jrow[q] == j) pd[S.Ppos[q]] = 1;
+      pd.resize(pd.size() + 64, 0); // read in whole blocks of 64
       dn.Pdiag = up(pd);
     }
     auto pack = [](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, size_t nstream, int &nchunk) {
@@ -421,7 +499,14 @@ void racgpu_network::upload() {
     if (h.i_Grain0 > 0) for (int g : {h.i_Grain0, h.i_GrainM, h.i_GrainP}) if (g > 0) cls[g - 1] = 2;
     for (int g : h.grain) cls[g - 1] = 3;
     dn.s_tolclass = up(cls);
+    std::vector<int8_t> chg(nS);
+    for (int i = 0; i < nS; ++i) chg[i] = (int8_t)h.elements[i][0];
+    dn.s_charge = up(chg);
   }
+  dn.i_H2 = h.idx10[0] - 1;
+  dn.r_h2form = -1; // chem_cal_rates stores the coefficient of every itype-0 and every gH-first itype-63 reaction in turn: the last one stays
+  for (int r = 0; r < nR; ++r)
+    if (h.R[r].itype == 0 || (h.R[r].itype == 63 && h.R[r].rname[0] == "gH")) dn.r_h2form = r;
   HIP_OK(hipEventCreate(&ev0));
   HIP_OK(hipEventCreate(&ev1));
   { void *d = nullptr; HIP_OK(hipMalloc(&d, sizeof(DevNet))); HIP_OK(hipMemcpy(d, &dn, sizeof(DevNet), hipMemcpyHostToDevice)); dev_allocs.push_back(d); dn_dev = (DevNet *)d; }
@@ -442,6 +527,7 @@ void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   ws.Dinv = alloc((size_t)slots * dn.npad);
   ws.rtol = alloc((size_t)slots * dn.npad);
   ws.atol = alloc((size_t)slots * dn.npad);
+  ws.ygood = alloc((size_t)slots * dn.npad);
   void *c = nullptr;
   HIP_OK(hipMalloc(&c, 64));
   ws_allocs.push_back(c);
@@ -480,6 +566,7 @@ static DevParams to_dev(const racgpu_params *p) {
   P.tol_j = p->tol_policy_j > 0 ? p->tol_policy_j : 1;
   P.max_steps_per_cell = p->max_steps_per_cell;
   P.max_runtime_allowed = p->max_runtime_allowed;
+  P.rt_cost_f = p->rt_cost_f; P.rt_cost_jac = p->rt_cost_jac; P.rt_cost_lu = p->rt_cost_lu;
   P.n_record = racgpu_n_record(p, 0.0, p->t_max);
   if (const char *e = std::getenv("RACGPU_DEBUG_TRACE")) P.debug_max_calls = std::atoi(e);
   cfode_bdf(P);
@@ -586,6 +673,7 @@ void racgpu_params_default(racgpu_params *p) {
   p->RTOL = 1e-4; p->ATOL = 1e-30; p->t_max = 1e6; p->dt_first_step = 1e-8; p->ratio_tstep = 1.1;
   p->max_runtime_allowed = 60.0; p->Diff2DesorRatio = 0.5; p->special_gH_E_diff = 225.0;
   p->mxstep_per_interval = 6000; p->steps_reset_solver = 50; p->tol_policy_j = 1; p->max_steps_per_cell = 0;
+  p->rt_cost_f = 47e-6; p->rt_cost_jac = 10.4e-3; p->rt_cost_lu = 1.0e-3;
 }
 
 int racgpu_n_record(const racgpu_params *p, double t0, double t_max) {
@@ -601,7 +689,10 @@ int racgpu_set_tolerances(const racgpu_network *h, const racgpu_params *p, int32
     case 2: r = std::fmin(p->RTOL * 1e1, 1e-4); a = std::fmin(p->ATOL * 1e5, 1e-25); rT = 1e-2; aT = 1e-1; break;
     case 3: r = std::fmin(p->RTOL * 1e2, 1e-4); a = std::fmin(p->ATOL * 1e10, 1e-20); rT = 1e-3; aT = 1e0; break;
     case 4: r = std::fmin(p->RTOL * 1e2, 1e-4); a = std::fmin(p->ATOL * 1e10, 1e-18); rT = 1e-3; aT = 1e0; break;
-    default: r = std::fmin(p->RTOL * std::pow(2.0, j), 1e-3); a = std::fmin(p->ATOL * std::pow(1e2, j), 1e-15); rT = 1e-2; aT = 1e0;
+    default: { // x**j with integer j: repeated squaring, as flang's runtime evaluates it
+      auto powi = [](double a, int b) { double r = 1.0; for (;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; } return r; };
+      r = std::fmin(p->RTOL * powi(2.0, j), 1e-3); a = std::fmin(p->ATOL * powi(1e2, j), 1e-15); rT = 1e-2; aT = 1e0;
+    }
   }
   for (int i = 0; i < n.nS; ++i) { rtol[i] = r; atol[i] = a; }
   rtol[n.nS] = rT; atol[n.nS] = aT;
@@ -640,7 +731,7 @@ int racgpu_rates(racgpu_network *h, const racgpu_params *p, const double *cells,
     HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dr(rates, (size_t)ncell * h->dn.nR * 8, RACGPU_MEM_HOST, false);
-    hipLaunchKernelGGL(k_rates, dim3((unsigned)ncell), dim3(64), 0, h->stream, h->dn_dev, h->dp_dev, (const double *)dc.d, (double *)dr.d);
+    hipLaunchKernelGGL(k_rates, dim3((unsigned)ncell), dim3(64), 0, h->stream, h->dn_dev, h->dp_dev, (const double *)dc.d, (double *)dr.d, (double *)nullptr);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(h->stream));
     dr.copy_out();
@@ -739,33 +830,91 @@ double racgpu_last_kernel_ms(const racgpu_network *h) {
   return ms;
 }
 
-int racgpu_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell, const double *cells, double *y, double *t_final,
-                       int32_t *quality, int64_t *stats, double *record, double *touts, int mem) {
+// One chem_evol_solve pass over ncell cells whose buffers are all in device memory (any of the outputs may be null).
+// Chunks the batch so that the per-cell rate vectors stay below 8 GB; one k_rates + one k_solve launch per chunk.
+struct PassBufs {
+  const double *cells; double *y; const double *t0; const int *tolj; double *t_final; int *quality; long long *stats;
+  double *record, *touts, *cell_out;
+};
+static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const PassBufs &B, int flags, bool use_hints, bool first_timed) {
+  const size_t nS = h->dn.nS;
+  const size_t lds = lds_bytes(h->dn);
+  const long per_cu = std::max<long>(1, std::min<long>(8, (long)(160 * 1024 / lds)));
+  const long slots = std::min<long>(ncell, per_cu * h->cu_count);
+  const long chunk_cells = std::max<long>(slots, std::min<long>(ncell, (long)(8e9 / (8.0 * h->dn.nR)))); // <= 8 GB of rates
+  h->ensure_workspace(slots, chunk_cells);
+  // optional longest-expected-first order, per chunk (indices relative to the chunk)
+  const bool hinted = use_hints && (int64_t)h->cost_hints.size() == ncell;
+  if (hinted) {
+    if (h->order_cap < ncell) {
+      HIP_OK(hipStreamSynchronize(h->stream));
+      if (h->order_dev) (void)hipFree(h->order_dev);
+      HIP_OK(hipMalloc((void **)&h->order_dev, (size_t)ncell * sizeof(int)));
+      h->order_cap = ncell;
+    }
+    std::vector<int> order((size_t)ncell);
+    for (long c0 = 0; c0 < ncell; c0 += chunk_cells) {
+      const long nc = std::min<long>(chunk_cells, ncell - c0);
+      for (long i = 0; i < nc; ++i) order[c0 + i] = (int)i;
+      const double *cost = h->cost_hints.data() + c0;
+      std::stable_sort(order.begin() + c0, order.begin() + c0 + nc, [&](int a, int b) { return cost[a] > cost[b]; });
+    }
+    HIP_OK(hipMemcpyAsync(h->order_dev, order.data(), (size_t)ncell * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream)); // 'order' lives on this stack frame
+  }
+  for (long c0 = 0; c0 < ncell; c0 += chunk_cells) {
+    const long nc = std::min<long>(chunk_cells, ncell - c0);
+    const double *cells_c = B.cells + (size_t)c0 * RACGPU_NPAR;
+    // pass 1: rate coefficients of every cell of the chunk (one wave per cell)
+    hipLaunchKernelGGL(k_rates, dim3((unsigned)nc), dim3(64), 0, h->stream, h->dn_dev, h->dp_dev, cells_c, h->ws.rates,
+                       B.cell_out ? B.cell_out + (size_t)c0 * RACGPU_NOUT : nullptr);
+    HIP_OK(hipGetLastError());
+    // pass 2: the persistent integrator
+    HIP_OK(hipMemsetAsync(h->ws.counter, 0, sizeof(int), h->stream));
+    if (c0 == 0 && first_timed) HIP_OK(hipEventRecord(h->ev0, h->stream));
+    SolveArgs A{};
+    A.ncell = (int)nc; A.flags = flags; A.cells = cells_c; A.yio = B.y + (size_t)c0 * nS;
+    A.t0 = B.t0 ? B.t0 + c0 : nullptr; A.tolj = B.tolj ? B.tolj + c0 : nullptr;
+    A.t_final = B.t_final ? B.t_final + c0 : nullptr; A.quality = B.quality ? B.quality + c0 : nullptr;
+    A.stats = B.stats ? B.stats + (size_t)c0 * RACGPU_NSTAT : nullptr;
+    A.record = B.record ? B.record + (size_t)c0 * P.n_record * (nS + 1) : nullptr;
+    A.touts = B.touts ? B.touts + (size_t)c0 * P.n_record : nullptr;
+    A.cell_out = B.cell_out ? B.cell_out + (size_t)c0 * RACGPU_NOUT : nullptr;
+    A.order = hinted ? h->order_dev + c0 : nullptr;
+    hipLaunchKernelGGL(k_solve, dim3((unsigned)std::min<long>(slots, nc)), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, A);
+    HIP_OK(hipGetLastError());
+  }
+}
+
+static void push_params(racgpu_network *h, const DevParams &P) {
+  HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream)); // P lives on the caller's stack frame
+}
+
+int racgpu_evol_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell, const double *cells, double *y, const double *t0,
+                            const int32_t *tol_j, double *t_final, int32_t *quality, int64_t *stats, double *record, double *touts,
+                            double *cell_out, int flags, int mem) {
   if (!h) return fail("null network");
   if (ncell <= 0) return 0;
   if (ncell > 0x7fffffffLL) return fail("ncell exceeds 2^31-1");
+  if (!cells || !y) return fail("cells and y must not be null");
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
+    push_params(h, P);
     const size_t nS = h->dn.nS;
-    const size_t lds = lds_bytes(h->dn);
-    const long per_cu = std::max<long>(1, std::min<long>(8, (long)(160 * 1024 / lds)));
-    const long slots = std::min<long>((long)ncell, per_cu * h->cu_count);
-    const long chunk_cells = std::max<long>(slots, std::min<long>((long)ncell, (long)(8e9 / (8.0 * h->dn.nR)))); // <= 8 GB of rates
-    h->ensure_workspace(slots, chunk_cells);
     std::vector<double> trace_host;
-    DevBuf dtrace(nullptr, 0, RACGPU_MEM_HOST, false);
+    std::unique_ptr<DevBuf> dtrace;
     h->ws.trace = nullptr;
     if (P.debug_max_calls > 0) {
       trace_host.assign((size_t)P.debug_max_calls * 8, 0.0);
-      new (&dtrace) DevBuf(trace_host.data(), trace_host.size() * 8, RACGPU_MEM_HOST, true);
-      h->ws.trace = (double *)dtrace.d;
+      dtrace = std::make_unique<DevBuf>(trace_host.data(), trace_host.size() * 8, RACGPU_MEM_HOST, true);
+      h->ws.trace = (double *)dtrace->d;
     }
-    DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, mem, true), dy(y, ncell * nS * 8, mem, true), dt(t_final, ncell * 8, mem, false),
-        dq(quality, ncell * 4, mem, false), ds(stats, ncell * RACGPU_NSTAT * 8, mem, false),
-        drec(record, (size_t)ncell * P.n_record * (nS + 1) * 8, mem, false), dto(touts, (size_t)ncell * P.n_record * 8, mem, false);
+    DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, mem, true), dy(y, ncell * nS * 8, mem, true), dt0(t0, ncell * 8, mem, true),
+        dj(tol_j, ncell * 4, mem, true), dt(t_final, ncell * 8, mem, false), dq(quality, ncell * 4, mem, false),
+        ds(stats, ncell * RACGPU_NSTAT * 8, mem, false), drec(record, (size_t)ncell * P.n_record * (nS + 1) * 8, mem, false),
+        dto(touts, (size_t)ncell * P.n_record * 8, mem, false), dout(cell_out, (size_t)ncell * RACGPU_NOUT * 8, mem, true);
     int *marker_host = nullptr;
     h->ws.marker = nullptr;
     const char *dbgwait = std::getenv("RACGPU_DEBUG_WAIT");
@@ -774,40 +923,9 @@ int racgpu_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell,
       *marker_host = 0;
       HIP_OK(hipHostGetDevicePointer((void **)&h->ws.marker, marker_host, 0));
     }
-    // optional longest-expected-first order, per chunk (indices relative to the chunk)
-    const bool hinted = (int64_t)h->cost_hints.size() == ncell;
-    if (hinted) {
-      if (h->order_cap < (long)ncell) {
-        HIP_OK(hipStreamSynchronize(h->stream));
-        if (h->order_dev) (void)hipFree(h->order_dev);
-        HIP_OK(hipMalloc((void **)&h->order_dev, (size_t)ncell * sizeof(int)));
-        h->order_cap = (long)ncell;
-      }
-      std::vector<int> order((size_t)ncell);
-      for (long c0 = 0; c0 < (long)ncell; c0 += chunk_cells) {
-        const long nc = std::min<long>(chunk_cells, (long)ncell - c0);
-        for (long i = 0; i < nc; ++i) order[c0 + i] = (int)i;
-        const double *cost = h->cost_hints.data() + c0;
-        std::stable_sort(order.begin() + c0, order.begin() + c0 + nc, [&](int a, int b) { return cost[a] > cost[b]; });
-      }
-      HIP_OK(hipMemcpy(h->order_dev, order.data(), (size_t)ncell * sizeof(int), hipMemcpyHostToDevice));
-    }
-    for (long c0 = 0; c0 < (long)ncell; c0 += chunk_cells) {
-      const long nc = std::min<long>(chunk_cells, (long)ncell - c0);
-      const double *cells_c = (const double *)dc.d + (size_t)c0 * RACGPU_NPAR;
-      // pass 1: rate coefficients of every cell of the chunk (one wave per cell)
-      hipLaunchKernelGGL(k_rates, dim3((unsigned)nc), dim3(64), 0, h->stream, h->dn_dev, h->dp_dev, cells_c, h->ws.rates);
-      HIP_OK(hipGetLastError());
-      // pass 2: the persistent integrator
-      HIP_OK(hipMemsetAsync(h->ws.counter, 0, sizeof(int), h->stream));
-      if (c0 == 0) HIP_OK(hipEventRecord(h->ev0, h->stream));
-      hipLaunchKernelGGL(k_solve, dim3((unsigned)std::min<long>(slots, nc)), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, (int)nc, cells_c,
-                         (double *)dy.d + (size_t)c0 * nS, dt.d ? (double *)dt.d + c0 : nullptr, dq.d ? (int *)dq.d + c0 : nullptr,
-                         ds.d ? (long long *)ds.d + (size_t)c0 * RACGPU_NSTAT : nullptr,
-                         drec.d ? (double *)drec.d + (size_t)c0 * P.n_record * (nS + 1) : nullptr,
-                         dto.d ? (double *)dto.d + (size_t)c0 * P.n_record : nullptr, hinted ? h->order_dev + c0 : nullptr);
-      HIP_OK(hipGetLastError());
-    }
+    PassBufs B{(const double *)dc.d, (double *)dy.d, (const double *)dt0.d, (const int *)dj.d, (double *)dt.d, (int *)dq.d, (long long *)ds.d,
+               (double *)drec.d, (double *)dto.d, (double *)dout.d};
+    solve_pass(h, P, (long)ncell, B, flags, true, true);
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     if (dbgwait) { // developer aid: watch the progress word; give up (and leave the process) instead of hanging
@@ -823,17 +941,116 @@ int racgpu_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell,
     }
     if (mem == RACGPU_MEM_HOST) {
       HIP_OK(hipStreamSynchronize(h->stream));
-      dy.copy_out(); dt.copy_out(); dq.copy_out(); ds.copy_out(); drec.copy_out(); dto.copy_out();
+      dy.copy_out(); dt.copy_out(); dq.copy_out(); ds.copy_out(); drec.copy_out(); dto.copy_out(); dout.copy_out();
     }
     if (P.debug_max_calls > 0) {
       HIP_OK(hipStreamSynchronize(h->stream));
-      dtrace.copy_out();
+      dtrace->copy_out();
       for (int i = 0; i < P.debug_max_calls; ++i) {
         const double *tr = &trace_host[(size_t)i * 8];
         std::fprintf(stderr, "[racgpu trace] call %3d tn=%.6e h=%.6e hu=%.6e nq=%g kflag=%g nst=%g nfe=%g nje/nlu=%g\n", i, tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6], tr[7]);
       }
     }
   });
+}
+
+int racgpu_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell, const double *cells, double *y, double *t_final,
+                       int32_t *quality, int64_t *stats, double *record, double *touts, int mem) {
+  return racgpu_evol_solve_batch(h, p, ncell, cells, y, nullptr, nullptr, t_final, quality, stats, record, touts, nullptr, 0, mem);
+}
+
+int racgpu_calc_cells(racgpu_network *h, const racgpu_params *p, int32_t nlocal_iter, int64_t ncell, const double *cells, double *y,
+                      double *t_final, int32_t *quality, int64_t *stats, double *cell_out, int mem) {
+  if (!h) return fail("null network");
+  if (ncell <= 0) return 0;
+  if (ncell > 0x7fffffffLL) return fail("ncell exceeds 2^31-1");
+  if (!cells || !y) return fail("cells and y must not be null");
+  if (nlocal_iter < 1) return fail("nlocal_iter must be >= 1");
+  return guarded([&] {
+    h->upload();
+    racgpu_params pj = *p;
+    pj.tol_policy_j = 1;
+    DevParams P = to_dev(&pj);
+    push_params(h, P);
+    h->ws.trace = nullptr; h->ws.marker = nullptr;
+    const size_t nS = h->dn.nS;
+    const long n = (long)ncell;
+    // the loop needs t_final, quality, stats and cell_out whether or not the caller wants them
+    auto dalloc = [&](size_t bytes) { void *d = nullptr; HIP_OK(hipMalloc(&d, std::max<size_t>(bytes, 8))); return d; };
+    struct Scoped { std::vector<void *> v; ~Scoped() { for (void *q : v) (void)hipFree(q); } } own;
+    auto scratch = [&](size_t bytes) { void *d = dalloc(bytes); own.v.push_back(d); return d; };
+    DevBuf dc(cells, (size_t)n * RACGPU_NPAR * 8, mem, true), dy(y, n * nS * 8, mem, true), dt(t_final, n * 8, mem, false),
+        dq(quality, n * 4, mem, false), ds(stats, n * RACGPU_NSTAT * 8, mem, false), dout(cell_out, (size_t)n * RACGPU_NOUT * 8, mem, true);
+    double *t_d = dt.d ? (double *)dt.d : (double *)scratch(n * 8);
+    int *q_d = dq.d ? (int *)dq.d : (int *)scratch(n * 4);
+    long long *s_d = ds.d ? (long long *)ds.d : (long long *)scratch(n * RACGPU_NSTAT * 8);
+    double *o_d = dout.d ? (double *)dout.d : (double *)scratch((size_t)n * RACGPU_NOUT * 8);
+    PassBufs B{(const double *)dc.d, (double *)dy.d, nullptr, nullptr, t_d, q_d, s_d, nullptr, nullptr, o_d};
+    solve_pass(h, P, n, B, 0, true, true);
+    HIP_OK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    if (nlocal_iter > 1) {
+      std::vector<double> tf((size_t)n), cl((size_t)n * RACGPU_NPAR);
+      std::vector<int> ql((size_t)n);
+      std::vector<long long> st((size_t)n * RACGPU_NSTAT);
+      std::vector<char> done((size_t)n, 0);
+      HIP_OK(hipMemcpyAsync(cl.data(), dc.d, cl.size() * 8, hipMemcpyDeviceToHost, h->stream));
+      for (int j = 2; j <= nlocal_iter; ++j) {
+        HIP_OK(hipMemcpyAsync(tf.data(), t_d, tf.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(ql.data(), q_d, ql.size() * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(st.data(), s_d, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        // who goes on (src/disk.f90:1706-1714, 1724-1728, 1784-1788): the previous iteration got past the one before it,
+        // produced a usable record, and ended flagged before half of the cell's t_max
+        std::vector<int> sel;
+        for (long c = 0; c < n; ++c) {
+          if (done[c]) continue;
+          const long long *s = &st[(size_t)c * RACGPU_NSTAT];
+          const double tmax_this = cl[(size_t)c * RACGPU_NPAR + RACGPU_P_TMAX] > 0.0 ? cl[(size_t)c * RACGPU_NPAR + RACGPU_P_TMAX] : p->t_max;
+          const bool stopped = (int)s[RACGPU_S_NITER] < j - 1 /* "does not proceed" left NITER behind */ || s[RACGPU_S_ISAV] <= 1 ||
+                               ql[c] == 0 || tf[c] >= 0.5 * tmax_this;
+          if (stopped) { done[c] = 1; continue; }
+          sel.push_back((int)c);
+        }
+        if (sel.empty()) break;
+        const long m = (long)sel.size();
+        int *sel_d = (int *)scratch(m * 4);
+        double *cells_c = (double *)scratch((size_t)m * RACGPU_NPAR * 8), *y_c = (double *)scratch(m * nS * 8), *t0_c = (double *)scratch(m * 8),
+               *tf_c = (double *)scratch(m * 8), *out_c = (double *)scratch((size_t)m * RACGPU_NOUT * 8);
+        int *q_c = (int *)scratch(m * 4);
+        long long *st_c = (long long *)scratch((size_t)m * RACGPU_NSTAT * 8);
+        HIP_OK(hipMemcpyAsync(sel_d, sel.data(), m * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_gather_pass, dim3((unsigned)m), dim3(64), 0, h->stream, (int)m, sel_d, (int)nS, (const double *)dc.d, (const double *)dy.d,
+                           (const double *)t_d, cells_c, y_c, t0_c);
+        HIP_OK(hipGetLastError());
+        racgpu_params pk = *p;
+        pk.tol_policy_j = j;
+        DevParams Pk = to_dev(&pk);
+        push_params(h, Pk); // also keeps 'sel' alive until its copy has completed
+        PassBufs Bc{cells_c, y_c, t0_c, nullptr, tf_c, q_c, st_c, nullptr, nullptr, out_c};
+        solve_pass(h, Pk, m, Bc, RACGPU_F_RECTIFY, false, false);
+        hipLaunchKernelGGL(k_merge_pass, dim3((unsigned)m), dim3(64), 0, h->stream, (int)m, sel_d, (int)nS, j, (const double *)y_c, (const double *)tf_c,
+                           (const int *)q_c, (const long long *)st_c, (const double *)out_c, (double *)dy.d, t_d, q_d, s_d, o_d);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(h->ev1, h->stream));
+      }
+    }
+    HIP_OK(hipStreamSynchronize(h->stream));
+    if (mem == RACGPU_MEM_HOST) { dy.copy_out(); dt.copy_out(); dq.copy_out(); ds.copy_out(); dout.copy_out(); }
+  });
+}
+
+int racgpu_rectify_abundances(const racgpu_network *h, int64_t ncell, double *y) {
+  if (!h) return fail("null network");
+  const HostNetwork &n = h->net;
+  const int iE = n.idx10[2];
+  if (iE <= 0) return fail("network has no E-");
+  for (int64_t c = 0; c < ncell; ++c) {
+    double *yc = y + c * n.nS, q = 0.0;
+    for (int i = 0; i < n.nS; ++i) q += yc[i] * (double)n.elements[i][0];
+    yc[iE - 1] = yc[iE - 1] + q;
+  }
+  return 0;
 }
 
 } // extern "C"

@@ -38,6 +38,7 @@ RG_DEV double bload_f64(rsrc_t r, int voff, int soff) { return __builtin_bit_cas
 RG_DEV unsigned long long bload_u64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
 RG_DEV uint32_t bload_u32(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
 RG_DEV uint16_t bload_u16(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+RG_DEV uint8_t bload_u8(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0); }
 RG_DEV void bstore_f64(rsrc_t r, int voff, int soff, double v) {
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
@@ -86,7 +87,10 @@ RG_DEV double dev_branching(int itype, double A, double B, double C, double T0, 
   return isnan(b) ? 0.0 : b;
 }
 
-RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restrict__ cell, double *__restrict__ rates, int lane) {
+// rh2 (may be null): where the cell's R_H2_form_rate_coeff goes -- the coefficient, still per second, of the last H2-formation
+// reaction (itype 0, or 63 with gH first), which the reference stores as a side effect (:804, :891)
+RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restrict__ cell, double *__restrict__ rates, int lane,
+                      double *__restrict__ rh2 = nullptr) {
   const double Tgas = cell[0], Tdust = cell[1], n_gas = cell[2], D2H = cell[6], sites = cell[7];
   const double T300 = Tgas / 300.0;
   const double Tred = cst::kB_SI * Tgas / (cst::eCharge_SI * cst::eCharge_SI * cst::Coulomb_SI / (cell[3] * 1e-2));
@@ -165,6 +169,7 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
         break;
       default: k = 0.0;
     }
+    if (rh2 && r == N.r_h2form) *rh2 = k;
     k = k * cst::SecPerYear;
     if (gptr(N.r_nreac)[r] == 2 && it < 60) k = k * n_gas;
     rates[r] = k;
@@ -188,16 +193,22 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
   wave_sync();
 }
 
+RG_DEV double dev_powi(double a, int b) { // x**j with integer j as flang evaluates it (repeated squaring, compiler-rt __powidf2)
+  double r = 1.0;
+  for (;;) { if (b & 1) r *= a; b /= 2; if (b == 0) break; a *= a; }
+  return r;
+}
+
 // chem_set_solver_flags_alt(j), reference src/chemistry.f90:205-268 (species part; T slot returned separately)
-RG_DEV void dev_tolerances(const DevNet &N, const DevParams &P, double d2h, double *__restrict__ rtol, double *__restrict__ atol,
+RG_DEV void dev_tolerances(const DevNet &N, const DevParams &P, int j, double d2h, double *__restrict__ rtol, double *__restrict__ atol,
                            double &rT, double &aT, int lane) {
   double r, a;
-  switch (P.tol_j) {
+  switch (j) {
     case 1: r = P.RTOL; a = P.ATOL; rT = 1e-3; aT = 1e-1; break;
     case 2: r = fmin(P.RTOL * 1e1, 1e-4); a = fmin(P.ATOL * 1e5, 1e-25); rT = 1e-2; aT = 1e-1; break;
     case 3: r = fmin(P.RTOL * 1e2, 1e-4); a = fmin(P.ATOL * 1e10, 1e-20); rT = 1e-3; aT = 1e0; break;
     case 4: r = fmin(P.RTOL * 1e2, 1e-4); a = fmin(P.ATOL * 1e10, 1e-18); rT = 1e-3; aT = 1e0; break;
-    default: r = fmin(P.RTOL * pow(2.0, (double)P.tol_j), 1e-3); a = fmin(P.ATOL * pow(1e2, (double)P.tol_j), 1e-15); rT = 1e-2; aT = 1e0;
+    default: r = fmin(P.RTOL * dev_powi(2.0, j), 1e-3); a = fmin(P.ATOL * dev_powi(1e2, j), 1e-15); rT = 1e-2; aT = 1e0;
   }
   for (int i = lane; i < N.nS; i += 64) {
     const int c = gptr(N.s_tolclass)[i];

@@ -2,6 +2,7 @@
 //
 // What is mirrored, and where it lives in the reference:
 //   output-time loop, restart/error policy, quality flags   chem_evol_solve            src/chemistry.f90:391-588
+//   hand-off record (last record without NaN)               calc_this_cell             src/disk.f90:1716-1733
 //   tolerance loosening after ISTATE -4/-5                  ode_solver_error_handling  src/chemistry.f90:297-377
 //   driver blocks A-H for ITASK=4 (TCRIT=HMAX=t_max)        DLSODES                    src/opkdmain.f:3069-3588
 //   one step in Nordsieck form, order/step selection        DSTODE                     src/opkda1.f:746-1124
@@ -18,14 +19,24 @@ namespace racgpu {
 struct CellCtx {
   double *y, *savf, *acor, *ewt, *wx;                          // LDS, nS doubles each
   double *yh, *Pv, *Lv, *Uv, *Dinv, *rates, *rtol, *atol;      // this cell's HBM slices
+  int lane, n, npad;
+  int *marker;    // developer aid: host-visible progress word, or null
+};
+
+// Per-cell constants and the per-phase cycle counters live in LDS and are read where they are used: as kernel-long
+// register values they (with hoisted constants) took ~100 VGPRs away from the factorisation.  Declared volatile and
+// accessed by name, so every access is one ds_read/ds_write on the LDS address space (a pointer or reference to a
+// __shared__ object is generic, and volatile accesses through it become flat_load/flat_store).
+struct WaveConst {
   double nsite;   // ratioDust2HnucNum * SitesPerGrain
   double Tgas, rT, aT;
-  int lane, n, npad;
   double inv_neq; // 1 / (nS + 1)
-  int *marker;    // developer aid: host-visible progress word, or null
-  mutable long long cyc_rhs, cyc_jac, cyc_lu, cyc_solve; // shader-clock cycles spent per phase (s_memtime)
-  mutable long long cyc_lu_part[4]; // LU split: column scatter, LDS pivots, register (dense) pivots, column finish
+  long long cyc[8]; // shader-clock cycles per phase (s_memtime): f(y), Jacobian, LU, triangular solves; then the LU split:
+                    // column scatter, LDS pivots, register (dense) pivots, column finish
 };
+enum { CYC_RHS = 0, CYC_JAC, CYC_LU, CYC_SOLVE, CYC_LU_PART };
+static __shared__ volatile WaveConst g_wc;
+RG_DEV void cyc_add(int k, long long d) { g_wc.cyc[k] = g_wc.cyc[k] + d; }
 
 RG_DEV long long dev_clock() { return (long long)__builtin_readcyclecounter(); }
 
@@ -50,7 +61,7 @@ template <typename V>
 RG_DEV double dev_vnorm(const CellCtx &c, V v) { // DVNORM over NEQ = nS+1 entries, the T entry being zero
   double s = 0.0;
   for (int i = c.lane; i < c.n; i += 64) { const double q = v(i) * c.ewt[i]; s += q * q; }
-  return sqrt(wave_sum(s) * c.inv_neq);
+  return sqrt(wave_sum(s) * g_wc.inv_neq);
 }
 
 RG_DEV void dev_set_order(const DevParams &P, Lsodes &s) { // DSTODE label 150
@@ -59,26 +70,37 @@ RG_DEV void dev_set_order(const DevParams &P, Lsodes &s) { // DSTODE label 150
   s.conit = 0.5 / (s.nq + 2);
 }
 
+// The wave's HBM vectors (Nordsieck columns, tolerances, hand-off record) are addressed through buffer resources:
+// base in SGPRs, lane part lane*8 in ONE VGPR, everything else (column, block of 64) in the scalar/immediate offset.
+// With plain pointers hipcc keeps one 64-bit per-lane address per (column, block) alive across the whole kernel.
+// A column holds npad = 64*ceil(n/64) doubles, so whole blocks may be read and written without a bound test where
+// only HBM is involved; entries >= n of a column are never used.
+RG_DEV int col_off(const CellCtx &c, int j) { return j * c.npad * 8; } // byte offset of Nordsieck column j (0-based)
+
 RG_DEV void dev_rescale(const CellCtx &c, Lsodes &s, double rh, bool apply_hmin) { // DSTODE labels 170/175
   if (apply_hmin) rh = fmax(rh, 0.0); // RH = MAX(RH, HMIN/ABS(H)) with HMIN = 0
   rh = fmin(rh, s.rmax);
   rh = rh / fmax(1.0, fabs(s.h) * s.hmxi * rh);
+  const rsrc_t bY = mkbuf(c.yh);
+  const int l8 = c.lane * 8;
   double r = 1.0;
   for (int j = 2; j <= s.l; ++j) {
     r = r * rh;
-    double *col = c.yh + (size_t)(j - 1) * c.npad;
-    for (int i = c.lane; i < c.n; i += 64) col[i] = col[i] * r;
+    const int co = col_off(c, j - 1);
+    for (int i0 = 0; i0 < c.n; i0 += 64) bstore_f64(bY, l8, co + i0 * 8, bload_f64(bY, l8, co + i0 * 8) * r);
   }
   s.h = s.h * rh; s.rc = s.rc * rh; s.ialth = s.l;
 }
 
-// YH <- YH * Pascal (sign = +1, also loads y <- YH(:,1)) or its inverse (sign = -1); DSTODE :865-874, :956-962
+// YH <- YH * Pascal (forward) or its inverse; DSTODE :865-874, :956-962
 RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward) {
   const int nq = s.nq;
-  for (int i = c.lane; i < c.n; i += 64) {
+  const rsrc_t bY = mkbuf(c.yh);
+  const int l8 = c.lane * 8;
+  for (int i0 = 0; i0 < c.n; i0 += 64) {
     double col[kMaxord + 1];
 #pragma unroll
-    for (int j = 0; j <= kMaxord; ++j) col[j] = (j <= nq) ? c.yh[(size_t)j * c.npad + i] : 0.0;
+    for (int j = 0; j <= kMaxord; ++j) col[j] = (j <= nq) ? bload_f64(bY, l8, col_off(c, j) + i0 * 8) : 0.0;
 #pragma unroll
     for (int jb = 1; jb <= kMaxord; ++jb) {
       if (jb > nq) break;
@@ -88,7 +110,7 @@ RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward) {
     }
 #pragma unroll
     for (int j = 0; j < kMaxord; ++j)
-      if (j < nq) c.yh[(size_t)j * c.npad + i] = col[j];
+      if (j < nq) bstore_f64(bY, l8, col_off(c, j) + i0 * 8, col[j]);
   }
 }
 
@@ -105,13 +127,16 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
     if (rcont > kRbig && s.iplost == 1) jok = false;
     else {
       bool lost = false;
-      for (int e = c.lane; e < N.nnzJ; e += 64) {
-        double pij = c.Pv[e];
-        const bool dg = gptr(N.Pdiag)[e]; // P is stored in permuted-column order
+      const rsrc_t bP = mkbuf(c.Pv), bD = mkbuf(N.Pdiag);
+      const int l8 = c.lane * 8;
+      for (int e0 = 0; e0 < N.nnzJ; e0 += 64) { // (the wave's slice of P ends at nnzJ: the next slot's slice follows directly)
+        double pij = bload_f64(bP, l8, e0 * 8);
+        const bool in = e0 + c.lane < N.nnzJ;
+        const bool dg = in && bload_u8(bD, c.lane, e0) != 0; // P is stored in permuted-column order
         if (dg) { pij = pij - 1.0; if (fabs(pij) < kPsmall) lost = true; }
         pij = pij * rcon;
         if (dg) pij = pij + 1.0;
-        c.Pv[e] = pij;
+        if (in) bstore_f64(bP, l8, e0 * 8, pij);
       }
       if (wave_any(lost)) { s.iplost = 1; s.conmin = fmin(fabs(s.con0), s.conmin); }
     }
@@ -119,20 +144,26 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   if (!jok) {
     s.jcur = 1; s.nje++; s.nslj = s.nst; s.iplost = 0; s.conmin = fabs(con);
     dev_mark(c, 3000);
-    { const long long t0 = dev_clock(); dev_build_P<true>(N, c.rates, c.nsite, c.y, con, true, c.Pv, c.lane); c.cyc_jac += dev_clock() - t0; }
+    { const long long t0 = dev_clock(); dev_build_P<true>(N, c.rates, g_wc.nsite, c.y, con, true, c.Pv, c.lane); cyc_add(CYC_JAC, dev_clock() - t0); }
     dev_mark(c, 3001);
   }
   s.nlu++; s.con0 = con; s.ierpj = 0;
   wave_sync();
-  { const long long t0 = dev_clock(); if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, c.cyc_lu_part)) s.ierpj = 1; c.cyc_lu += dev_clock() - t0; }
+  {
+    const long long t0 = dev_clock();
+    long long part[4] = {0, 0, 0, 0};
+    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, part)) s.ierpj = 1;
+    cyc_add(CYC_LU, dev_clock() - t0);
+    for (int k = 0; k < 4; ++k) cyc_add(CYC_LU_PART + k, part[k]);
+  }
   s.ierpj = uniform_i(wave_any(s.ierpj != 0) ? 1 : 0);
 }
 
 // One step.  Returns kflag (0, -1, -2).  Structure follows the restatement validated on the CPU side; every
 // expression keeps the reference's operand order.
 RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s) {
-  const int n = c.n, lane = c.lane, npad = c.npad;
-  double *yh = c.yh;
+  const int n = c.n, lane = c.lane, l8 = c.lane * 8;
+  const rsrc_t bY = mkbuf(c.yh);
   const double told = s.tn;
   double delp = 0.0, del = 0.0, dsm = 0.0, rh = 0.0;
   int ncf = 0, m = 0, iredo = 0;
@@ -158,8 +189,8 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     bool converged = false;
     for (int pass = 0; pass < 4; ++pass) { // label 220: re-entered after a P refresh (at most twice: rescaled P, then fresh J)
       m = 0;
-      for (int i = lane; i < n; i += 64) c.y[i] = yh[i];
-      { const long long t0 = dev_clock(); dev_rhs(N, c.rates, c.nsite, gptr(N.r_C), c.y, c.savf, lane); c.cyc_rhs += dev_clock() - t0; } s.nfe++;
+      for (int i0 = 0; i0 < n; i0 += 64) { const double v = bload_f64(bY, l8, i0 * 8); if (i0 + lane < n) c.y[i0 + lane] = v; }
+      { const long long t0 = dev_clock(); dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
       dev_mark(c, 2200 + pass);
       if (s.ipup > 0) {
         dev_prjs(N, c, s);
@@ -170,13 +201,21 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       for (int i = lane; i < n; i += 64) c.acor[i] = 0.0;
       bool fail410 = false;
       for (;;) {
-        for (int i = lane; i < n; i += 64) c.y[i] = s.h * c.savf[i] - (yh[npad + i] + c.acor[i]);
+        for (int i0 = 0; i0 < n; i0 += 64) {
+          const double y1 = bload_f64(bY, l8, col_off(c, 1) + i0 * 8);
+          const int i = i0 + lane;
+          if (i < n) c.y[i] = s.h * c.savf[i] - (y1 + c.acor[i]);
+        }
         dev_mark(c, 2400 + m);
-        { const long long t0 = dev_clock(); dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane); c.cyc_solve += dev_clock() - t0; }
+        { const long long t0 = dev_clock(); dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane); cyc_add(CYC_SOLVE, dev_clock() - t0); }
         dev_mark(c, 2500 + m);
         del = dev_vnorm(c, [&](int i) { return c.y[i]; });
         const double el1 = P.elco[s.nq][1];
-        for (int i = lane; i < n; i += 64) { const double a = c.acor[i] + c.y[i]; c.acor[i] = a; c.y[i] = yh[i] + el1 * a; }
+        for (int i0 = 0; i0 < n; i0 += 64) {
+          const double y0 = bload_f64(bY, l8, i0 * 8);
+          const int i = i0 + lane;
+          if (i < n) { const double a = c.acor[i] + c.y[i]; c.acor[i] = a; c.y[i] = y0 + el1 * a; }
+        }
         if (m != 0) s.crate = fmax(0.2 * s.crate, del / delp);
         const double dcon = del * fmin(1.0, 1.5 * s.crate) / (P.tesco[s.nq][2] * s.conit);
         if (dcon <= 1.0) { converged = true; break; }
@@ -184,7 +223,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (m == kMaxcor) { fail410 = true; break; }
         if (m >= 2 && del > 2.0 * delp) { fail410 = true; break; }
         delp = del;
-        { const long long t0 = dev_clock(); dev_rhs(N, c.rates, c.nsite, gptr(N.r_C), c.y, c.savf, lane); c.cyc_rhs += dev_clock() - t0; } s.nfe++;
+        { const long long t0 = dev_clock(); dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
       }
       if (converged) break;
       if (fail410 && s.jcur != 1) { s.icf = 1; s.ipup = 1; continue; }
@@ -216,9 +255,9 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (s.kflag == -10) { s.kflag = -1; break; }
         rh = 0.1;
         s.h = s.h * rh;
-        for (int i = lane; i < n; i += 64) c.y[i] = yh[i];
-        dev_rhs(N, c.rates, c.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe++;
-        for (int i = lane; i < n; i += 64) yh[npad + i] = s.h * c.savf[i];
+        for (int i0 = 0; i0 < n; i0 += 64) { const double v = bload_f64(bY, l8, i0 * 8); if (i0 + lane < n) c.y[i0 + lane] = v; }
+        dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe++;
+        for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, 1) + i0 * 8, s.h * c.savf[i]); }
         s.ipup = 1; s.ialth = 5;
         if (s.nq != 1) { s.nq = 1; s.l = 2; dev_set_order(P, s); }
         continue;
@@ -226,17 +265,23 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       iredo = 2; rhup = 0.0; consider = true;
     } else {
       s.kflag = 0; iredo = 0; s.nst++; s.hu = s.h; s.nqu = s.nq; s.qsum += s.nq;
-      for (int j = 1; j <= s.l; ++j) {
-        const double elj = P.elco[s.nq][j];
-        double *col = yh + (size_t)(j - 1) * npad;
-        for (int i = lane; i < n; i += 64) col[i] = col[i] + elj * c.acor[i];
+      for (int i0 = 0; i0 < n; i0 += 64) { // element-outer: acor is read from LDS once per block
+        const int i = i0 + lane;
+        const double ac = i < n ? c.acor[i] : 0.0;
+        for (int j = 1; j <= s.l; ++j) {
+          const int o = col_off(c, j - 1) + i0 * 8;
+          bstore_f64(bY, l8, o, bload_f64(bY, l8, o) + P.elco[s.nq][j] * ac);
+        }
       }
       s.ialth--;
       if (s.ialth == 0) { // label 520
         rhup = 0.0;
         if (s.l != s.lmax) {
-          const double *top = yh + (size_t)(s.lmax - 1) * npad;
-          for (int i = lane; i < n; i += 64) c.savf[i] = c.acor[i] - top[i];
+          for (int i0 = 0; i0 < n; i0 += 64) {
+            const double top = bload_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8);
+            const int i = i0 + lane;
+            if (i < n) c.savf[i] = c.acor[i] - top;
+          }
           const double dup = dev_vnorm(c, [&](int i) { return c.savf[i]; }) / P.tesco[s.nq][3];
           const double exup = 1.0 / (s.l + 1);
           rhup = 1.0 / (1.4 * pow(dup, exup) + 0.0000014);
@@ -244,8 +289,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         consider = true;
       } else {
         if (s.ialth <= 1 && s.l != s.lmax) {
-          double *top = yh + (size_t)(s.lmax - 1) * npad;
-          for (int i = lane; i < n; i += 64) top[i] = c.acor[i];
+          for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8, c.acor[i]); }
         }
         goto done700;
       }
@@ -256,8 +300,13 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       const double rhsm = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
       double rhdn = 0.0;
       if (s.nq != 1) {
-        const double *last = yh + (size_t)(s.l - 1) * npad;
-        const double ddn = dev_vnorm(c, [&](int i) { return last[i]; }) / P.tesco[s.nq][1];
+        double q = 0.0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+          const double last = bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8);
+          const int i = i0 + lane;
+          if (i < n) { const double w = last * c.ewt[i]; q += w * w; }
+        }
+        const double ddn = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][1];
         const double exdn = 1.0 / s.nq;
         rhdn = 1.0 / (1.3 * pow(ddn, exdn) + 0.0000013);
       }
@@ -268,8 +317,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         newq = s.l; rh = rhup;
         if (rh < 1.1) { s.ialth = 3; goto done700; }
         const double r = P.elco[s.nq][s.l] / s.l;
-        double *col = yh + (size_t)newq * npad;
-        for (int i = lane; i < n; i += 64) col[i] = c.acor[i] * r;
+        for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, newq) + i0 * 8, c.acor[i] * r); }
       } else {
         if (sel == 0) { newq = s.nq; rh = rhsm; }
         else { newq = s.nq - 1; rh = rhdn; if (s.kflag < 0 && rh > 1.0) rh = 1.0; }
@@ -296,34 +344,39 @@ done700: {
 
 RG_DEV void dev_intdy0(const CellCtx &c, const Lsodes &s, double t) { // y <- interpolant at t
   const double sf = (t - s.tn) / s.h;
-  for (int i = c.lane; i < c.n; i += 64) {
-    double d = c.yh[(size_t)(s.l - 1) * c.npad + i];
-    for (int j = s.nq - 1; j >= 0; --j) d = c.yh[(size_t)j * c.npad + i] + sf * d;
-    c.y[i] = d;
+  const rsrc_t bY = mkbuf(c.yh);
+  const int l8 = c.lane * 8;
+  for (int i0 = 0; i0 < c.n; i0 += 64) {
+    double d = bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8);
+    for (int j = s.nq - 1; j >= 0; --j) d = bload_f64(bY, l8, col_off(c, j) + i0 * 8) + sf * d;
+    if (i0 + c.lane < c.n) c.y[i0 + c.lane] = d;
   }
 }
 
 RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some weight is <= 0
   bool bad = false;
-  for (int i = c.lane; i < c.n; i += 64) {
-    const double e = c.rtol[i] * fabs(c.yh[i]) + c.atol[i];
-    if (e <= 0.0) bad = true;
-    c.ewt[i] = 1.0 / e;
+  const rsrc_t bY = mkbuf(c.yh), bR = mkbuf(c.rtol), bA = mkbuf(c.atol);
+  const int l8 = c.lane * 8;
+  for (int i0 = 0; i0 < c.n; i0 += 64) {
+    const double e = bload_f64(bR, l8, i0 * 8) * fabs(bload_f64(bY, l8, i0 * 8)) + bload_f64(bA, l8, i0 * 8);
+    if (i0 + c.lane < c.n) { if (e <= 0.0) bad = true; c.ewt[i0 + c.lane] = 1.0 / e; }
   }
-  const double eT = c.rT * fabs(c.Tgas) + c.aT;
+  const double Tg = g_wc.Tgas, eT = g_wc.rT * fabs(Tg) + g_wc.aT;
   if (eT <= 0.0) bad = true;
   return !wave_any(bad);
 }
 
 RG_DEV void dev_finish(const CellCtx &c, const Lsodes &s, double &t) { // label 580 / 400
-  for (int i = c.lane; i < c.n; i += 64) c.y[i] = c.yh[i];
+  const rsrc_t bY = mkbuf(c.yh);
+  for (int i0 = 0; i0 < c.n; i0 += 64) { const double v = bload_f64(bY, c.lane * 8, i0 * 8); if (i0 + c.lane < c.n) c.y[i0 + c.lane] = v; }
   t = s.tn;
 }
 
 // One DLSODES call, ITASK = 4.  On entry y (LDS) is the user's Y; on exit it is Y at t.
 RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s, double &t, double tout, int &istate) {
   const double u = kUround;
-  const int n = c.n, lane = c.lane;
+  const int n = c.n, lane = c.lane, l8 = c.lane * 8;
+  const rsrc_t bY = mkbuf(c.yh);
   if (istate != 1 && s.init == 0) { istate = -3; return; }
   if (istate == 1) { s.init = 0; if (tout == t) return; }
   if (istate == 3) {
@@ -335,28 +388,33 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
   if (istate == 1) { // Block C
     s.h0 = 0.0;
     s.tn = t; s.nst = 0; s.h = 1.0;
-    for (int i = lane; i < n; i += 64) c.yh[i] = c.y[i];
-    dev_rhs(N, c.rates, c.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe = 1;
-    for (int i = lane; i < n; i += 64) c.yh[c.npad + i] = c.savf[i];
+    for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, i0 * 8, c.y[i]); }
+    dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe = 1;
+    for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, 1) + i0 * 8, c.savf[i]); }
     if (!dev_ewset(c)) { istate = -3; return; }
-    for (int e = lane; e < N.nnzJ; e += 64) c.Pv[e] = 0.0;
+    { const rsrc_t bP = mkbuf(c.Pv); for (int e0 = 0; e0 < N.nnzJ; e0 += 64) if (e0 + lane < N.nnzJ) bstore_f64(bP, l8, e0 * 8, 0.0); }
     if ((s.tcrit - tout) * (tout - t) < 0.0) { istate = -3; return; }
     s.jstart = 0; s.nslj = 0; s.nje = 0; s.nlu = 0; s.nslast = 0; s.hu = 0.0; s.nqu = 0;
     {
       const double tdist = fabs(tout - t), w0 = fmax(fabs(t), fabs(tout));
       if (tdist < 2.0 * u * w0) { istate = -3; return; }
       double tol = 0.0;
-      for (int i = lane; i < n; i += 64) tol = fmax(tol, c.rtol[i]);
+      const rsrc_t bR = mkbuf(c.rtol), bA = mkbuf(c.atol);
+      for (int i0 = 0; i0 < n; i0 += 64) { const double r = bload_f64(bR, l8, i0 * 8); if (i0 + lane < n) tol = fmax(tol, r); }
 #pragma unroll
       for (int mm = 32; mm >= 1; mm >>= 1) tol = fmax(tol, __shfl_xor(tol, mm, 64));
-      tol = uniform_d(fmax(tol, c.rT));
+      tol = uniform_d(fmax(tol, g_wc.rT));
       if (tol <= 0.0) {
         double tl = 0.0;
-        for (int i = lane; i < n; i += 64) { const double ay = fabs(c.y[i]); if (ay != 0.0) tl = fmax(tl, c.atol[i] / ay); }
+        for (int i0 = 0; i0 < n; i0 += 64) {
+          const double a = bload_f64(bA, l8, i0 * 8);
+          const int i = i0 + lane;
+          if (i < n) { const double ay = fabs(c.y[i]); if (ay != 0.0) tl = fmax(tl, a / ay); }
+        }
 #pragma unroll
         for (int mm = 32; mm >= 1; mm >>= 1) tl = fmax(tl, __shfl_xor(tl, mm, 64));
         tol = uniform_d(tl);
-        if (c.Tgas != 0.0) tol = fmax(tol, c.aT / fabs(c.Tgas));
+        { const double Tg = g_wc.Tgas; if (Tg != 0.0) tol = fmax(tol, g_wc.aT / fabs(Tg)); }
       }
       tol = fmax(tol, 100.0 * u); tol = fmin(tol, 0.001);
       double sum = dev_vnorm(c, [&](int i) { return c.savf[i]; });
@@ -368,7 +426,7 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
     const double rh = fabs(s.h0) * s.hmxi;
     if (rh > 1.0) s.h0 = s.h0 / rh;
     s.h = s.h0;
-    for (int i = lane; i < n; i += 64) c.yh[c.npad + i] = s.h0 * c.yh[c.npad + i];
+    for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bY, l8, col_off(c, 1) + i0 * 8, s.h0 * bload_f64(bY, l8, col_off(c, 1) + i0 * 8));
   } else { // Block D
     s.nslast = s.nst;
     if ((s.tn - s.tcrit) * s.h > 0.0) { istate = -3; return; }
@@ -391,9 +449,13 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
     first = false;
     {
       double q = 0.0;
-      for (int i = lane; i < n; i += 64) { const double v = c.yh[i] * c.ewt[i]; q += v * v; }
-      const double vT = c.Tgas / (c.rT * fabs(c.Tgas) + c.aT);
-      const double tolsf = u * sqrt((wave_sum(q) + vT * vT) * c.inv_neq);
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const double y0 = bload_f64(bY, l8, i0 * 8);
+        const int i = i0 + lane;
+        if (i < n) { const double v = y0 * c.ewt[i]; q += v * v; }
+      }
+      const double Tg = g_wc.Tgas, vT = Tg / (g_wc.rT * fabs(Tg) + g_wc.aT);
+      const double tolsf = u * sqrt((wave_sum(q) + vT * vT) * g_wc.inv_neq);
       if (tolsf > 1.0) {
         if (s.nst == 0) { istate = -3; return; }
         istate = -2; dev_finish(c, s, t); return;
@@ -431,70 +493,99 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
   }
 }
 
-// chem_evol_solve for one cell.  y (LDS) in: abundances at t0 = 0; out: abundances at t_final.
-struct CellResult { double t_final; int quality, nerr, nrec_real; long long nst, nfe, nje, nlu, qsum; int nfail; };
+// chem_evol_solve for one cell.  y (LDS) in: abundances at t0; out: abundances at the end of the run.
+// ygood (HBM): the hand-off record, i.e. record(:, isav) of the caller's loop in calc_this_cell (reference
+// src/disk.f90:1716-1733): the last record whose T and H2 entries are not NaN.
+struct CellResult { double t_final, t_good; int quality, nerr, nrec_real, isav; long long nst, nfe, nje, nlu, qsum; int nfail; };
 
-RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const CellCtx &c, double t_max, int n_record,
-                                 double *__restrict__ record, double *__restrict__ touts, double *trace) {
+// The output loop's own scalars live in LDS and are read and written through a volatile view: between two DLSODES calls
+// they are touched a few times, while inside the call every register is wanted by the factorisation.
+struct EvolState {
+  double t, t_step, tout, t_good, rt_total, rt_last;
+  long long nst_acc, nfe_acc, nje_acc, nlu_acc;
+  int istate, nerr, nerr_c, qual, nrr, isav;
+};
+
+RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const CellCtx &c, double t0, double t_max, double dt_first,
+                                 int n_record, double *__restrict__ record, double *__restrict__ touts, double *__restrict__ ygood,
+                                 double *trace) {
   __shared__ Lsodes s_lds;
+  __shared__ volatile EvolState e; // accessed by name: a reference would be a generic pointer (flat_load/flat_store)
   Lsodes &s = s_lds;
   s = Lsodes{};
   s.trace = trace; s.trace_cap = P.debug_max_calls;
   s.tcrit = t_max; s.hmxi = (t_max > 0.0) ? 1.0 / t_max : 0.0; s.mxstep = P.mxstep > 0 ? P.mxstep : 500;
-  CellResult R{};
-  int istate = 1, nerr = 0, nerr_c = 0, qual = 0, nrr = 1;
-  double t = 0.0, t_step = P.dt_first_step, tout = t + t_step;
-  long long nst_acc = 0, nfe_acc = 0, nje_acc = 0, nlu_acc = 0;
+  e.istate = 1; e.nerr = 0; e.nerr_c = 0; e.qual = 0; e.nrr = 1; e.isav = 1;
+  e.t = t0; e.t_step = dt_first; e.tout = t0 + dt_first; e.t_good = t0;
+  e.nst_acc = 0; e.nfe_acc = 0; e.nje_acc = 0; e.nlu_acc = 0;
   // Deterministic stand-in for the reference's CPU-time guards (src/chemistry.f90:438, 480-491): the time the
-  // reference would have spent is MODELLED from the call counters with its measured per-call costs on one
-  // core (f 47 us, full Jacobian 10.4 ms, LU+solves ~1.0 ms per factorisation).
-  double rt_total = 0.0, rt_last = 1e300;
-  const double rt_max = P.max_runtime_allowed, rt_per_step = 5.0 / (double)n_record * rt_max;
+  // reference would have spent is MODELLED from the call counters with per-call costs (racgpu_params; defaults =
+  // the reference's measured costs on one core, SURVEY.md section 6: f 47 us, full Jacobian 10.4 ms, LU+solves
+  // ~1.0 ms per factorisation).
+  e.rt_total = 0.0; e.rt_last = 1e300;
   const int lane = c.lane, n = c.n, neq = c.n + 1;
-  if (touts) { if (lane == 0) touts[0] = t; }
-  if (record) { for (int i = lane; i < n; i += 64) record[i] = c.y[i]; if (lane == 0) record[n] = c.Tgas; }
+  if (touts) { if (lane == 0) touts[0] = t0; }
+  if (record) { for (int i = lane; i < n; i += 64) record[i] = c.y[i]; if (lane == 0) record[n] = g_wc.Tgas; }
   for (int i = 2; i <= n_record; ++i) {
-    if (tout >= t_max) tout = t_max;
+    double tout = e.tout;
+    if (tout >= s.tcrit) tout = s.tcrit;
+    int istate = e.istate;
     const bool restart = (istate == 1);
     const int nst0 = restart ? 0 : s.nst, nfe0 = restart ? 0 : s.nfe, nje0 = restart ? 0 : s.nje, nlu0 = restart ? 0 : s.nlu;
+    double t = e.t;
     dev_lsodes_call(N, P, c, s, t, tout, istate);
-    nst_acc += s.nst - nst0; nfe_acc += s.nfe - nfe0; nje_acc += s.nje - nje0; nlu_acc += s.nlu - nlu0;
-    const double rt_this = 47e-6 * (double)(s.nfe - nfe0) + 10.4e-3 * (double)(s.nje - nje0) + 1.0e-3 * (double)(s.nlu - nlu0);
-    rt_total += rt_this;
+    e.t = t;
+    e.nst_acc = e.nst_acc + (s.nst - nst0); e.nfe_acc = e.nfe_acc + (s.nfe - nfe0); e.nje_acc = e.nje_acc + (s.nje - nje0); e.nlu_acc = e.nlu_acc + (s.nlu - nlu0);
+    const double rt_this = P.rt_cost_f * (double)(s.nfe - nfe0) + P.rt_cost_jac * (double)(s.nje - nje0) + P.rt_cost_lu * (double)(s.nlu - nlu0);
+    e.rt_total = e.rt_total + rt_this;
     wave_sync();
     if (touts) { if (lane == 0) touts[i - 1] = t; }
-    if (record) { double *rec = record + (size_t)(i - 1) * neq; for (int k = lane; k < n; k += 64) rec[k] = c.y[k]; if (lane == 0) rec[n] = c.Tgas; }
-    nrr = i;
-    if (P.max_steps_per_cell > 0 && nst_acc >= P.max_steps_per_cell) break; // deterministic "Premature finish"
-    if (rt_max > 0.0) { // src/chemistry.f90:482-491 on modelled time
-      if (rt_this > fmax(10.0 * rt_last, 0.5 * rt_max) || rt_total > rt_max) break;
-      if (rt_this > rt_per_step) istate = 1;
-      rt_last = rt_this;
+    if (record) { double *rec = record + (size_t)(i - 1) * neq; for (int k = lane; k < n; k += 64) rec[k] = c.y[k]; if (lane == 0) rec[n] = g_wc.Tgas; }
+    e.nrr = i;
+    {
+      // the record calc_this_cell would hand back if the run ended here (src/disk.f90:1716-1721)
+      const double yh2 = N.i_H2 >= 0 ? c.y[N.i_H2] : 0.0;
+      if (!(isnan(yh2) || isnan(g_wc.Tgas))) {
+        e.isav = i; e.t_good = t;
+        const rsrc_t bG = mkbuf(ygood);
+        for (int i0 = 0; i0 < n; i0 += 64) { const int k = i0 + lane; if (k < n) bstore_f64(bG, lane * 8, i0 * 8, c.y[k]); }
+      }
     }
-    if (t >= t_max) break;
+    if (P.max_steps_per_cell > 0 && e.nst_acc >= P.max_steps_per_cell) break; // deterministic "Premature finish"
+    const double rt_max = P.max_runtime_allowed;
+    if (rt_max > 0.0) { // src/chemistry.f90:482-491 on modelled time
+      if (rt_this > fmax(10.0 * e.rt_last, 0.5 * rt_max) || e.rt_total > rt_max) break;
+      if (rt_this > 5.0 / (double)n_record * rt_max) istate = 1;
+      e.rt_last = rt_this;
+    }
+    if (t >= s.tcrit) break;
     if (istate < 0) {
-      nerr++; nerr_c++;
+      e.nerr = e.nerr + 1; e.nerr_c = e.nerr_c + 1;
       if (istate == -4 || istate == -5) { // loosen the offending component's tolerances
         const int idx = s.imxer;
         if (lane == 0) { c.rtol[idx] = fmin(c.rtol[idx] * 10.0, 1e-3); c.atol[idx] = fmin(c.atol[idx] * 100.0, 1e-20); }
         wave_sync();
       }
-      if (istate == -3) { qual += 256; break; }
-      if (nerr_c < 3) istate = 3; else { istate = 1; nerr_c = 0; }
+      if (istate == -3) { e.qual = e.qual + 256; break; }
+      if (e.nerr_c < 3) istate = 3; else { istate = 1; e.nerr_c = 0; }
     }
     {
-      bool bad = !(c.Tgas > 0.0);
+      bool bad = !(g_wc.Tgas > 0.0);
       if (N.i_gH2 >= 0 && fabs(c.y[N.i_gH2]) > 1.0) bad = true;
       if (N.i_gH2O >= 0 && fabs(c.y[N.i_gH2O]) > 1.0) bad = true;
       if (N.i_gH >= 0 && fabs(c.y[N.i_gH]) > 1.0) bad = true;
       if (N.i_H >= 0 && fabs(c.y[N.i_H]) > 2.0) bad = true;
       if (N.i_E >= 0 && fabs(c.y[N.i_E]) > 1.0) bad = true;
-      if (wave_any(bad)) { qual += 512; break; }
+      if (wave_any(bad)) { e.qual = e.qual + 512; break; }
     }
     if (P.steps_reset > 0 && i % P.steps_reset == 0) istate = 1;
-    t_step = t_step * P.ratio_tstep;
-    tout = t + t_step;
+    e.istate = istate;
+    const double t_step = e.t_step * P.ratio_tstep;
+    e.t_step = t_step;
+    e.tout = t + t_step;
   }
+  const int nrr = e.nrr;
+  const double t = e.t;
   dev_mark(c, 300 + nrr);
   if (touts) { if (lane == 0) for (int i = nrr + 1; i <= n_record; ++i) touts[i - 1] = t; }
   dev_mark(c, 400);
@@ -502,14 +593,16 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     for (int i = nrr + 1; i <= n_record; ++i) {
       double *rec = record + (size_t)(i - 1) * neq;
       for (int k = lane; k < n; k += 64) rec[k] = c.y[k];
-      if (lane == 0) rec[n] = c.Tgas;
+      if (lane == 0) rec[n] = g_wc.Tgas;
     }
   }
   dev_mark(c, 401);
-  if (nerr > (int)(0.1f * (float)n_record)) qual += 1;
-  if (t <= 0.5 * t_max) qual += 2;
-  R.t_final = t; R.quality = qual; R.nerr = nerr; R.nrec_real = nrr;
-  R.nst = nst_acc; R.nfe = nfe_acc; R.nje = nje_acc; R.nlu = nlu_acc; R.qsum = s.qsum; R.nfail = s.nfail;
+  int qual = e.qual;
+  if (e.nerr > (int)(0.1f * (float)n_record)) qual += 1;
+  if (t <= 0.5 * s.tcrit) qual += 2;
+  CellResult R{};
+  R.t_final = t; R.t_good = e.t_good; R.isav = e.isav; R.quality = qual; R.nerr = e.nerr; R.nrec_real = nrr;
+  R.nst = e.nst_acc; R.nfe = e.nfe_acc; R.nje = e.nje_acc; R.nlu = e.nlu_acc; R.qsum = s.qsum; R.nfail = s.nfail;
   return R;
 }
 

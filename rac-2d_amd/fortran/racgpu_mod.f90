@@ -11,14 +11,16 @@ module racgpu
   implicit none
   private
   public :: racgpu_params_t, type_chemical_evol_solver_params, chemsol_params, chemistry_configure_read
-  public :: RACGPU_NPAR, RACGPU_NSTAT, RACGPU_MEM_HOST, RACGPU_MEM_DEVICE
+  public :: RACGPU_NPAR, RACGPU_NSTAT, RACGPU_NOUT, RACGPU_MEM_HOST, RACGPU_MEM_DEVICE, RACGPU_F_RECTIFY
   public :: racgpu_network_load, racgpu_network_destroy, racgpu_network_dims, racgpu_species_name, &
             racgpu_species_index, racgpu_load_initial_abundances, racgpu_params_default, racgpu_n_record, &
             racgpu_set_tolerances, racgpu_init_abundances, racgpu_set_device, racgpu_device_count, &
-            racgpu_solve_batch, racgpu_set_cost_hints, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
+            racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_rectify_abundances, &
+            racgpu_set_cost_hints, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
   public :: racgpu_error_string, chemsol_to_c, c_string
 
-  integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 16, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
+  integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 20, RACGPU_NOUT = 3, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
+  integer, parameter :: RACGPU_F_RECTIFY = 1
 
   ! struct racgpu_params (include/racgpu.h)
   type, bind(c) :: racgpu_params_t
@@ -26,6 +28,7 @@ module racgpu
     integer(c_int32_t) :: mxstep_per_interval, steps_reset_solver, H2_form_use_moeq, evol_dust_size, &
                           use_special_gH_mobi, tol_policy_j
     integer(c_int64_t) :: max_steps_per_cell
+    real(c_double) :: rt_cost_f, rt_cost_jac, rt_cost_lu
   end type racgpu_params_t
 
   ! The namelist variable.  Component names and defaults follow the reference's declaration so that an
@@ -152,6 +155,36 @@ module racgpu
       integer(c_int), value :: mem
       integer(c_int) :: rc
     end function
+    ! chem_evol_solve per cell with its own t0 and tolerance policy j (continue runs; include/racgpu.h)
+    function racgpu_evol_solve_batch(h, p, ncell, cells, y, t0, tol_j, t_final, quality, stats, record, touts, cell_out, flags, mem) &
+        bind(c, name='racgpu_evol_solve_batch') result(rc)
+      import :: c_ptr, racgpu_params_t, c_int64_t, c_int
+      type(c_ptr), value :: h
+      type(racgpu_params_t), intent(in) :: p
+      integer(c_int64_t), value :: ncell
+      type(c_ptr), value :: cells, y, t0, tol_j, t_final, quality, stats, record, touts, cell_out
+      integer(c_int), value :: flags, mem
+      integer(c_int) :: rc
+    end function
+    ! the local-iteration loop of calc_this_cell (reference src/disk.f90:1651-1791) for a batch of cells
+    function racgpu_calc_cells(h, p, nlocal_iter, ncell, cells, y, t_final, quality, stats, cell_out, mem) &
+        bind(c, name='racgpu_calc_cells') result(rc)
+      import :: c_ptr, racgpu_params_t, c_int64_t, c_int32_t, c_int
+      type(c_ptr), value :: h
+      type(racgpu_params_t), intent(in) :: p
+      integer(c_int32_t), value :: nlocal_iter
+      integer(c_int64_t), value :: ncell
+      type(c_ptr), value :: cells, y, t_final, quality, stats, cell_out
+      integer(c_int), value :: mem
+      integer(c_int) :: rc
+    end function
+    function racgpu_rectify_abundances(h, ncell, y) bind(c, name='racgpu_rectify_abundances') result(rc)
+      import :: c_ptr, c_int64_t, c_double, c_int
+      type(c_ptr), value :: h
+      integer(c_int64_t), value :: ncell
+      real(c_double), dimension(*), intent(inout) :: y
+      integer(c_int) :: rc
+    end function
     ! scheduling hint for the following racgpu_solve_batch calls: expected work per cell, costliest cells first
     function racgpu_set_cost_hints(h, cost, ncell) bind(c, name='racgpu_set_cost_hints') result(rc)
       import :: c_ptr, c_double, c_int64_t, c_int
@@ -204,6 +237,15 @@ contains
   ! namelist values -> the C struct
   subroutine chemsol_to_c(p)
     type(racgpu_params_t), intent(out) :: p
+    ! switches of the reference this engine does not implement are refused, not ignored (DESIGN.md section 0)
+    if (chemsol_params%update_gH_params_realtime) then
+      write(*, '(A)') 'racgpu: chemsol_params%update_gH_params_realtime = .true. is not implemented'
+      stop 1
+    end if
+    if (chemsol_params%evolT) then
+      write(*, '(A)') 'racgpu: chemsol_params%evolT = .true. (gas temperature co-evolution) is not implemented'
+      stop 1
+    end if
     call racgpu_params_default(p)
     p%RTOL = chemsol_params%RTOL
     p%ATOL = chemsol_params%ATOL

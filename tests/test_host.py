@@ -18,7 +18,7 @@ def test_abi_exports_every_declared_symbol(racgpu):
     assert declared == set(racgpu.ABI_SYMBOLS), declared ^ set(racgpu.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert ctypes.sizeof(racgpu.ChemsolParams) == 8 * 8 + 6 * 4 + 8
+    assert ctypes.sizeof(racgpu.ChemsolParams) == 8 * 8 + 6 * 4 + 8 + 3 * 8
 
 
 @pytest.mark.parametrize("tag", GOLDEN_TAGS)
