@@ -6,21 +6,33 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path (rate coefficients + tolerance policy + the whole chem_evol_solve
-integration to t_max) over one batch of synthetic cells.  Workload (BASELINE.json configs[1]): 10 000
-synthetic cells per GPU, log-uniform T in [10,3000] K and n_H in [1e3,1e12] cm^-3 (rac-2d_amd/cells.py,
-seed 20240601 + rank), network rate06 "withoutgrain" (464 species, 4767 reactions), initial abundances
-ini_abund_waterice_loMetal.dat, template solver settings (RTOL 1e-4, ATOL 1e-30, t_max 1e6 yr,
-dt_first_step 1e-8, ratio 1.1, steps_reset_solver 50).  Cells shard embarrassingly: every rank solves its
-own 10 000 cells (weak scaling); the only exchange is ONE RCCL all-gather of the end-state abundances,
-inside the timed region.  Inputs are resident in HBM before the clock starts.
+integration of every cell to its t_max) over one batch of synthetic cell records.
 
-Scheduling: a few cells in 10^4 need 10-20x the median work.  As between two global
-iterations of the disk model, every pass hands the per-cell cycle counts it measured to the next one
-(racgpu_set_cost_hints), which then starts the costliest cells first; the hand-over is inside the timed region.
-The first warm-up pass has no history and runs in queue order: its rate is reported as
-config.queue_order_first_pass.  --no-hints keeps queue order throughout.  Results do not depend on the order.
+Workloads (--workload):
+  grid      (default) BASELINE.json configs[2]: the full synthetic Andrews-2009 grid, 200 columns x 100 cells = 20 000 cell
+            records (rac-2d_amd/cells.py::andrews_grid: n_H 1e3..6e12 cm^-3, T 8..5000 K, Av 1e-4..1e5, per-cell t_max by the
+            reference's orbit rule), network rate06_dipole_reformated_again_withgrain_lowH2Bind.dat (467 species, 4801
+            reactions), ini_abund_waterice_loMetal.dat, template solver settings (RTOL 1e-4, ATOL 1e-30, t_max0 1e6 yr,
+            dt_first_step 1e-8, ratio 1.1, steps_reset_solver 50).  --network default switches to the README-default
+            5830-reaction file.
+  synth10k  BASELINE.json configs[1]: 10 000 log-uniform random cells, rate06 "withoutgrain" network (round 1's line).
+
+Multi-GPU (--scaling):
+  weak      (default) every rank solves a whole grid of its own (rank r: the same disk with the gas mass scaled by 1 + r/16,
+            so no two ranks hold the same cells); per-GPU work is fixed as N grows.
+  strong    BASELINE.json configs[3]: ONE grid, cells dealt round-robin by expected cost over the ranks
+            (rac-2d_amd/sweep.py), total work fixed.
+Either way the only exchange is ONE RCCL all-gather of the end-state abundances, t_final, quality and counters, inside the
+timed region.  Inputs are resident in HBM before the clock starts.
+
+Scheduling: as between two global iterations of the disk model, every pass hands the per-cell cycle counts it measured to
+the next one (racgpu_set_cost_hints), which then starts the costliest cells first; the hand-over is inside the timed region.
+The first warm-up pass has no history and runs in queue order: its rate is reported as config.queue_order_first_pass.
 
 metric value = (accepted integrator steps summed over all cells and ranks) / (max over ranks of wall time).
+The line also carries: roofline (algorithmic bytes / k_solve time, HIP events on the launch stream), cpu_baseline (the
+reference's own Fortran binary on a bounded sample of the same cells, all host cores) and parity (the GPU's end state of
+those sample cells against the reference's: the second half of BASELINE.json's metric).
 """
 import argparse
 import importlib
@@ -36,8 +48,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 DATA = os.path.join(ROOT, "data")
-NETWORK = "rate06_dipole_reformated_again_withoutgrain.dat"
-INITIAL = "ini_abund_waterice_loMetal.dat"
+NETWORKS = {
+    "grain": "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat",
+    "default": "rate06_withgrain_lowH2Bind_hiOBind_lowCObind.dat",
+    "nograin": "rate06_dipole_reformated_again_withoutgrain.dat",
+    "rate12": "rate12_withGrain_lowH2Bind_hiObind.dat",
+}
+INITIAL = {"default": "ini_abund_waterice_loMetal_CO.dat"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -50,17 +67,29 @@ def algorithmic_bytes(nS, nR, nnzJ, nzl, nzu, nst, nfe, nje, nlu, qsum):
                   + 4.0 * (qsum + nst) * neq + 6.0 * nst * neq)
 
 
-def cpu_baseline(cells, y0_path, nst_gpu, max_seconds=30.0):
-    """The reference's own Fortran path (oracle/_ref/ref_driver, built from the unmodified sources in the
-    build container) on a bounded sample of the same cells, one process per host core.  Falls back to the C
-    restatement (kind "port").  Baseline only."""
+def _read_sections(fn):
+    d, cur = {}, None
+    for line in open(fn):
+        if line.startswith("#"):
+            cur = line.split()[1]
+            d[cur] = []
+        elif cur is not None:
+            d[cur].append(float(line))
+    return {k: np.array(v) for k, v in d.items()}
+
+
+def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS):
+    """The reference's own Fortran path (oracle/_ref/ref_driver, built from the unmodified sources in the build container)
+    on a bounded sample of the same cells, one process per host core.  Returns (cpu_baseline, parity).  Falls back to the
+    C restatement (kind "port", single thread).  Baseline and checker only: nothing here is on the product path."""
     cores = min(os.cpu_count() or 1, 16)
-    nsample = min(len(cells), 16 * cores)  # ~1 s per cell per core: 15-25 s of wall time
-    sample = cells[:nsample]
+    sample = cells[sample_idx]
+    nsample = len(sample)
     driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    ref = None
     if os.path.exists(driver):
         with tempfile.TemporaryDirectory() as td:
-            procs = []
+            procs, dirs = [], []
             t0 = time.perf_counter()
             for w in range(cores):
                 part = sample[w::cores]
@@ -68,46 +97,83 @@ def cpu_baseline(cells, y0_path, nst_gpu, max_seconds=30.0):
                     continue
                 d = os.path.join(td, "w%d" % w)
                 os.makedirs(d)
+                dirs.append((w, d, len(part)))
                 np.savetxt(os.path.join(d, "cells.txt"), part, fmt="%.17e")
                 with open(os.path.join(d, "run.nml"), "w") as f:
                     f.write("&ref_run\n chem_dir='%s/'\n network='%s'\n initial='%s'\n out_dir='%s'\n cell_file='%s'\n ncell=%d\n"
-                            " rtol=1D-4\n atol=1D-30\n dt_first_step=1D-8\n ratio_tstep=1.1D0\n t_max=1D6\n mxstep=6000\n"
-                            " steps_reset=50\n dump_jac=0\n solve=1\n/\n" % (DATA, NETWORK, INITIAL, d, os.path.join(d, "cells.txt"), len(part)))
+                            " rtol=%.17e\n atol=%.17e\n dt_first_step=%.17e\n ratio_tstep=%.17e\n t_max=%.17e\n mxstep=%d\n"
+                            " steps_reset=%d\n dump_jac=0\n solve=1\n/\n" % (
+                                DATA, network, initial, d, os.path.join(d, "cells.txt"), len(part), params.RTOL, params.ATOL,
+                                params.dt_first_step, params.ratio_tstep, params.t_max, params.mxstep_per_interval,
+                                params.steps_reset_solver))
                 procs.append(subprocess.Popen([driver, os.path.join(d, "run.nml")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
             ok = all(p.wait() == 0 for p in procs)
             dt = time.perf_counter() - t0
-        if ok:
-            steps = float(np.sum(nst_gpu[:nsample]))
-            return {"value": steps / dt, "unit": "cell-steps/s", "cores": cores, "kind": "reference",
-                    "sample": "%d cells of the same batch (first %d), reference Fortran/DLSODES binary, %d processes, %.1f s wall; "
+            if ok:
+                ref = {}
+                for w, d, m in dirs:
+                    for k in range(m):
+                        ref[w + k * cores] = _read_sections(os.path.join(d, "cell_%04d.txt" % (k + 1)))
+        if ref is not None:
+            steps = float(np.sum(gpu["nst"][sample_idx]))
+            base = {"value": steps / dt, "unit": "cell-steps/s", "cores": cores, "kind": "reference",
+                    "sample": "%d cells of the same batch (every %d-th), reference Fortran/DLSODES binary, %d processes, %.1f s wall; "
                               "steps counted with the GPU run's NST for the same cells (DLSODES zeroes its own counter at every solver reset)"
-                              % (nsample, nsample, min(cores, nsample), dt)}
+                              % (nsample, max(1, len(cells) // nsample), min(cores, nsample), dt)}
+            errs, tf_eq, q_eq = [], 0, 0
+            for k in range(nsample):
+                r = ref[k]
+                yr = r["yend"][:nS]
+                yg = gpu["y"][sample_idx[k]]
+                m = yr >= 1e-6
+                errs.append(float(np.max(np.abs(yg[m] - yr[m]) / yr[m])))
+                tf_eq += int(r["scalars"][0] == gpu["t_final"][sample_idx[k]])
+                q_eq += int(int(r["scalars"][1]) == int(gpu["quality"][sample_idx[k]]))
+            errs = np.array(errs)
+            parity = {"against": "reference Fortran/DLSODES end states of the cpu_baseline sample, same RTOL (%g); species with X >= 1e-6" % params.RTOL,
+                      "cells": nsample, "max_rel_err": float(errs.max()), "median_rel_err": float(np.median(errs)),
+                      "p90_rel_err": float(np.percentile(errs, 90)), "cells_within_1e-4": int((errs <= 1e-4).sum()),
+                      "t_final_equal": tf_eq, "quality_equal": q_eq,
+                      "note": "at RTOL 1e-4 the reference moves by 1e-5...1e-3 against its own 1-ulp-perturbed twin (tests/golden yend_ulp); "
+                              "the RTOL 1e-8 pin (<= 2e-6) is tests/test_gpu_parity.py::test_tight_tolerance_run_matches_the_reference_truth"}
+            return base, parity
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_ctypes as O
-    onet = O.Network(os.path.join(DATA, NETWORK))
-    y0 = onet.initial_abundances(y0_path)
+    onet = O.Network(os.path.join(DATA, network))
+    y0 = onet.initial_abundances(os.path.join(DATA, initial))
     op = O.default_params()
+    for f in ("RTOL", "ATOL", "t_max", "dt_first_step", "ratio_tstep", "mxstep_per_interval", "steps_reset_solver"):
+        setattr(op, f, getattr(params, f))
     t0 = time.perf_counter()
-    steps = 0
-    n = 0
-    for c in sample:
-        steps += onet.solve_cell(op, c, y0)["nst"]
+    steps, n, errs = 0, 0, []
+    for k in range(nsample):
+        o = onet.solve_cell(op, sample[k], y0)
+        steps += o["nst"]
         n += 1
-        if time.perf_counter() - t0 > max_seconds:
+        yr = o["y"][:nS]; m = yr >= 1e-6
+        errs.append(float(np.max(np.abs(gpu["y"][sample_idx[k]][m] - yr[m]) / yr[m])))
+        if time.perf_counter() - t0 > 30.0:
             break
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+    base = {"value": steps / dt, "unit": "cell-steps/s", "cores": 1, "kind": "port",
             "sample": "%d cells of the same batch, C restatement (oracle/), single thread, %.1f s" % (n, dt)}
+    parity = {"against": "C restatement (oracle/) end states, species with X >= 1e-6", "cells": n, "max_rel_err": float(np.max(errs)),
+              "median_rel_err": float(np.median(errs))}
+    return base, parity
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cells", type=int, default=10000, help="cells per GPU (default: BASELINE configs[1])")
+    ap.add_argument("--workload", choices=("grid", "synth10k"), default="grid")
+    ap.add_argument("--network", choices=sorted(NETWORKS), default=None, help="default: grain for grid, nograin for synth10k")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--cells", type=int, default=0, help="synth10k: cells per GPU (default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hints", action="store_true", help="take cells in queue order in every pass (no cost feedback)")
+    ap.add_argument("--nlocal-iter", type=int, default=1, help="> 1: the caller's local-iteration loop (racgpu_calc_cells) instead of one chem_evol_solve pass")
     args = ap.parse_args()
 
     import torch
@@ -124,23 +190,53 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     R = importlib.import_module("rac-2d_amd")
+    sweep = importlib.import_module("rac-2d_amd.sweep")
     R.set_device(local_rank)
-    net = R.Network(os.path.join(DATA, NETWORK))
+    netkey = args.network or ("grain" if args.workload == "grid" else "nograin")
+    network = NETWORKS[netkey]
+    initial = INITIAL.get(netkey, "ini_abund_waterice_loMetal.dat")
+    net = R.Network(os.path.join(DATA, network))
     nS = net.nSpecies
-    y0 = net.load_initial_abundances(os.path.join(DATA, INITIAL))
+    y0 = net.load_initial_abundances(os.path.join(DATA, initial))
     params = R.default_params()
-    ncell = args.cells
-    cells_h = R.cells.synth_batch(ncell, seed=20240601 + rank)
+    if netkey == "rate12":
+        params.RTOL = 1e-6; params.t_max = 1e7  # BASELINE.json configs[4]
+    if args.workload == "grid":
+        if args.scaling == "strong" and world > 1:
+            full = R.cells.andrews_grid()
+            # expected cost: denser cells take more steps; deal round-robin by it so every rank gets the same mix
+            order = sweep.interleaved_order(full[:, R.cells.P_NGAS], world)
+            lo, hi = sweep.partition(len(full), world, rank)
+            cells_h = np.ascontiguousarray(full[order[lo:hi]])
+        else:
+            cells_h = R.cells.andrews_grid(Md=2e-2 * (1.0 + rank / 16.0))
+        wl = ("configs[2]: full synthetic Andrews-2009 grid, 200 columns x 100 cells = 20000 cell records (n_H 1e3..6e12 cm^-3, "
+              "T 8..5000 K, per-cell t_max by the orbit rule), %s network (%s: %d species, %d reactions), %s, t_max0=%g yr, RTOL=%g, "
+              "steps_reset_solver=50" % (netkey, network, nS, net.nReactions, initial, params.t_max, params.RTOL))
+    else:
+        ncell0 = args.cells or 10000
+        cells_h = R.cells.synth_batch(ncell0, seed=20240601 + rank)
+        wl = ("configs[1]: %d synthetic cells per GPU (log-uniform T in [10,3000] K, n_H in [1e3,1e12] cm^-3), %s network (%s: %d species, "
+              "%d reactions), %s, t_max=%g yr, RTOL=%g, steps_reset_solver=50" % (ncell0, netkey, network, nS, net.nReactions, initial, params.t_max, params.RTOL))
+    ncell = len(cells_h)
     yinit_h = net.init_abundances(y0, cells_h)
 
     dev = torch.device("cuda", local_rank)
     cells_d = torch.from_numpy(cells_h).to(dev)
     yinit_d = torch.from_numpy(yinit_h).to(dev)
+    # one flat result block per rank: [y | t_final | quality | stats] as f64, so that ONE collective moves everything
+    ncol = nS + 2 + R.NSTAT
     y_d = torch.empty_like(yinit_d)
     tfin_d = torch.zeros(ncell, dtype=torch.float64, device=dev)
     qual_d = torch.zeros(ncell, dtype=torch.int32, device=dev)
     stats_d = torch.zeros((ncell, R.NSTAT), dtype=torch.int64, device=dev)
-    gathered = torch.empty((world * ncell, nS), dtype=torch.float64, device=dev) if world > 1 else None
+    maxn = ncell
+    if world > 1:
+        t = torch.tensor([ncell], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        maxn = int(t.item())
+    block_d = torch.zeros((maxn, ncol), dtype=torch.float64, device=dev)
+    gathered = torch.empty((world * maxn, ncol), dtype=torch.float64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream(dev)
     net.set_stream(stream.cuda_stream)
 
@@ -148,15 +244,22 @@ def main():
 
     def one_pass():
         y_d.copy_(yinit_d)
-        net.evol_solve_batch_device(params, ncell, cells_d.data_ptr(), y_d.data_ptr(), tfin_d.data_ptr(), qual_d.data_ptr(), stats_d.data_ptr())
+        if args.nlocal_iter > 1:
+            net.calc_cells_device(params, args.nlocal_iter, ncell, cells_d.data_ptr(), y_d.data_ptr(), tfin_d.data_ptr(), qual_d.data_ptr(), stats_d.data_ptr())
+        else:
+            net.evol_solve_batch_device(params, ncell, cells_d.data_ptr(), y_d.data_ptr(), tfin_d.data_ptr(), qual_d.data_ptr(), stats_d.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, y_d)  # the path's single exchange: RCCL over xGMI
+            block_d[:ncell, :nS] = y_d
+            block_d[:ncell, nS] = tfin_d
+            block_d[:ncell, nS + 1] = qual_d.to(torch.float64)
+            block_d[:ncell, nS + 2:] = stats_d.to(torch.float64)
+            dist.all_gather_into_tensor(gathered, block_d)  # the path's single exchange: RCCL over xGMI
         torch.cuda.synchronize(dev)
         kernel_ms.append(net.last_kernel_ms())
         if not args.no_hints:
             # cost feedback, as between two global iterations of the disk model: the cycles each cell took in this pass
             # order the next pass (costliest first).  Part of the pass, so it is inside the timed region.
-            net.set_cost_hints(stats_d[:, 8].cpu().numpy().astype(np.float64))
+            net.set_cost_hints(stats_d[:, R.S_CYC_TOTAL].cpu().numpy().astype(np.float64))
 
     def barrier():
         if world > 1:
@@ -193,25 +296,27 @@ def main():
         abytes = algorithmic_bytes(nS, net.nReactions, net.nnzJ, net.nzl, net.nzu, nst, nfe, nje, nlu, qsum)
         kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = abytes / (kms * 1e-3) / 1e9
-        # HBM bytes per launch.  PMC counters cannot be read from inside this process; the figure is the per-cell-step
-        # traffic of the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same workload
-        # (profiles/r1_pmc_calibration.json, corrected as MI355X_MICROARCH.md prescribes) times this launch's cell-steps.
+        # HBM bytes per launch.  PMC counters cannot be read from inside this process; the figure is the per-cell-step traffic
+        # of the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same workload (profiles/r2_pmc_calibration.json,
+        # FETCH_SIZE corrected by the factor measured with a micro-kernel of known bytes and the same 8 B/lane buffer loads)
+        # times this launch's cell-steps: "calibrated, not measured".
         traffic, traffic_src = None, None
         try:
-            cal = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_calibration.json")))
-            if cal["workload"]["cells_per_gpu"] == ncell and cal["workload"]["network"] == NETWORK:
+            cal = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_calibration.json")))
+            if cal["workload"]["name"] == args.workload and cal["workload"]["network"] == network:
                 traffic = cal["bytes_per_cell_step_corrected"] * nst
-                traffic_src = "profiles/r1_pmc_calibration.json: %.0f B per cell-step x %d cell-steps" % (cal["bytes_per_cell_step_corrected"], int(nst))
+                traffic_src = ("calibrated, not measured in this run: profiles/r2_pmc_calibration.json, %.0f B per cell-step x %d cell-steps"
+                               % (cal["bytes_per_cell_step_corrected"], int(nst)))
         except Exception:
             pass
+        cyc = stats[:, R.S_CYC_TOTAL].astype(np.float64)
         out = {
             "metric": "cell-steps/s (whole node)", "value": steps_all / t_all, "unit": "cell-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_all / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic cells per GPU (log-uniform T in [10,3000] K, n_H in [1e3,1e12] cm^-3), "
-                                   "rate06 no-grain network (%s: %d species, %d reactions), %s, t_max=1e6 yr, RTOL=1e-4, "
-                                   "steps_reset_solver=50" % (ncell, NETWORK, nS, net.nReactions, INITIAL),
-                       "cells_per_gpu": ncell, "parallelism": "cells sharded over %d GPU(s), one RCCL all-gather at output" % world,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl, "cells_per_gpu": ncell,
+                       "parallelism": "cells sharded over %d GPU(s) (%s), one RCCL all-gather of abundances + t_final + quality + counters at output" % (world, args.scaling),
+                       "local_iterations": args.nlocal_iter,
                        "scheduling": ("costliest-first from the previous pass's per-cell cycle counts (racgpu_set_cost_hints)" if hinted
                                       else "queue order (no previous pass to take cost hints from)"),
                        # rank 0's first warm-up pass runs in queue order: its rate is the no-feedback figure
@@ -225,13 +330,18 @@ def main():
             "nfe_per_step": nfe / max(nst, 1), "nlu_per_step": nlu / max(nst, 1), "nje_per_step": nje / max(nst, 1),
             "mean_order": qsum / max(nst, 1), "cells_with_quality_flags": int((qual != 0).sum()),
             # share of each wave's shader-clock cycles per phase (in-kernel s_memtime brackets, summed over cells)
-            "phase_cycle_share": {k: float(stats[:, i].sum()) / max(float(stats[:, 8].sum()), 1.0)
+            "phase_cycle_share": {k: float(stats[:, i].sum()) / max(float(cyc.sum()), 1.0)
                                   for k, i in (("rhs", 9), ("jacobian", 10), ("lu", 11), ("tri_solve", 12),
                                                ("lu_scatter", 13), ("lu_lds_pivots", 14), ("lu_reg_pivots", 15))},
-            "wave_cycles_per_cell_step": float(stats[:, 8].sum()) / max(nst, 1.0),
+            "wave_cycles_per_cell_step": float(cyc.sum()) / max(nst, 1.0),
+            "costliest_cell_over_mean": float(cyc.max() / max(cyc.mean(), 1.0)),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cells_h, os.path.join(DATA, INITIAL), stats[:, 0])
+            cores = min(os.cpu_count() or 1, 16)
+            nsample = min(ncell, 16 * cores)
+            sample_idx = np.arange(nsample) * (ncell // nsample) + (ncell // nsample) // 2  # spread over the whole batch
+            gpu = {"y": y_d.cpu().numpy(), "t_final": tfin_d.cpu().numpy(), "quality": qual, "nst": stats[:, 0]}
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cells_h, sample_idx, network, initial, params, gpu, nS)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -84,7 +84,7 @@ def andrews_density(r_au, z_au, Md=2e-2, rin=0.1, rout=200.0, rc=80.0, hc=10.0, 
 
 
 def andrews_grid(ncol=200, nz=100, rmin=0.1, rmax=200.0, zr_max=0.6, star_mass_msun=0.6, t_max0=1e6,
-                 n_orbit_tmax=1e5, use_fixed_tmax=False, a_cm=1e-5, return_geometry=False):
+                 n_orbit_tmax=1e5, use_fixed_tmax=False, a_cm=1e-5, return_geometry=False, Md=2e-2):
     """BASELINE configs[2]: ~20 k frozen cell records of a full 2-D disk grid.
 
     The real grid needs the reference's Monte-Carlo radiative transfer (out of scope), so every field below is a
@@ -109,13 +109,14 @@ def andrews_grid(ncol=200, nz=100, rmin=0.1, rmax=200.0, zr_max=0.6, star_mass_m
                  f_CO = min(1, (1e-5 N / 1e15)^-0.75); f_H2O = min(1, (1e-6 N / 1e17)^-0.5);
                  f_OH = min(1, (1e-7 N / 1e17)^-0.5), N the column in the respective direction
       t_max      tmax_this(omega_Kepler) (orbit rule, src/disk.f90:2078-2085) unless use_fixed_tmax
+    Md scales the gas mass (bench.py gives every rank of a weak-scaling run a disk of its own).
     """
     r = rmin * (rmax / rmin) ** ((np.arange(ncol) + 0.5) / ncol)            # column centres
     mu = zr_max * (nz - 0.5 - np.arange(nz)) / nz                            # z/r, top -> bottom
     R, MU = np.meshgrid(r, mu, indexing="ij")                                 # [ncol, nz]
     Z = R * MU
-    n, H = andrews_density(R, Z)
-    n_mid, _ = andrews_density(r, 0.0 * r)
+    n, H = andrews_density(R, Z, Md=Md)
+    n_mid, _ = andrews_density(r, 0.0 * r, Md=Md)
     n = np.maximum(n, 1e2)
     from math import erfc
     erfc_v = np.vectorize(erfc)

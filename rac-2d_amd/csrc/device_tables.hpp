@@ -87,6 +87,7 @@ struct DevWork { // per-cell workspace, all f64, cell-major
   double *U;       // [ncell][nzu]
   double *Dinv;    // [ncell][npad]
   double *rtol, *atol; // [ncell][npad]
+  double *acor, *ewt; // [ncell][npad] accumulated correction and inverse error weights of the step in progress
   double *ygood;   // [ncell][npad] the last record whose T and H2 entries are not NaN (the hand-off record)
   int *counter;    // work queue head
   double *trace;   // developer aid: [debug_max_calls][8] step log of cell 0, or null

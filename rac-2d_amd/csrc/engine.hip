@@ -32,8 +32,8 @@ static int fail(const std::string &m) { g_err = m; return -1; }
 // ---------------------------------------------------------------------------------------------------------
 // kernels (one wave per workgroup, one cell per wave)
 // ---------------------------------------------------------------------------------------------------------
-struct LdsViews { double *y, *savf, *acor, *ewt, *wx; };
-__device__ __forceinline__ LdsViews carve(double *lds, int nlds) { return {lds, lds + nlds, lds + 2 * nlds, lds + 3 * nlds, lds + 4 * nlds}; }
+struct LdsViews { double *y, *savf, *wx; }; // three LDS vectors per wave: 11.1 KB for 464 species, 12 waves per CU
+__device__ __forceinline__ LdsViews carve(double *lds, int nlds) { return {lds, lds + nlds, lds + 2 * nlds}; }
 
 __global__ __launch_bounds__(64) void k_rates(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, const double *cells, double *rates_out,
                                               double *cell_out) {
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
   const int lane = threadIdx.x, slot = blockIdx.x, n = N.nS, nlds = (n + 1) & ~1;
   LdsViews v = carve(lds, nlds);
   CellCtx c;
-  c.y = v.y; c.savf = v.savf; c.acor = v.acor; c.ewt = v.ewt; c.wx = v.wx;
+  c.y = v.y; c.savf = v.savf; c.wx = v.wx;
+  c.acor = W.acor + (size_t)slot * N.npad; c.ewt = W.ewt + (size_t)slot * N.npad;
   c.rates = nullptr; c.yh = W.yh + (size_t)slot * 6 * N.npad; c.Pv = W.P + (size_t)slot * N.nnzJ;
   c.Lv = W.L + (size_t)slot * N.nzl; c.Uv = W.U + (size_t)slot * N.nzu; c.Dinv = W.Dinv + (size_t)slot * N.npad;
   c.rtol = W.rtol + (size_t)slot * N.npad; c.atol = W.atol + (size_t)slot * N.npad;
@@ -528,6 +529,8 @@ void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   ws.rtol = alloc((size_t)slots * dn.npad);
   ws.atol = alloc((size_t)slots * dn.npad);
   ws.ygood = alloc((size_t)slots * dn.npad);
+  ws.acor = alloc((size_t)slots * dn.npad);
+  ws.ewt = alloc((size_t)slots * dn.npad);
   void *c = nullptr;
   HIP_OK(hipMalloc(&c, 64));
   ws_allocs.push_back(c);
@@ -721,7 +724,7 @@ int racgpu_set_stream(racgpu_network *h, void *s) {
   return 0;
 }
 
-static size_t lds_bytes(const DevNet &dn) { return (size_t)5 * ((dn.nS + 1) & ~1) * sizeof(double); }
+static size_t lds_bytes(const DevNet &dn) { return (size_t)3 * ((dn.nS + 1) & ~1) * sizeof(double); }
 
 int racgpu_rates(racgpu_network *h, const racgpu_params *p, const double *cells, int64_t ncell, double *rates) {
   if (!h) return fail("null network");
@@ -839,7 +842,8 @@ struct PassBufs {
 static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const PassBufs &B, int flags, bool use_hints, bool first_timed) {
   const size_t nS = h->dn.nS;
   const size_t lds = lds_bytes(h->dn);
-  const long per_cu = std::max<long>(1, std::min<long>(8, (long)(160 * 1024 / lds)));
+  // waves per CU: 3 per SIMD by registers (<= 168 VGPRs, tests/test_build_resources.py), and what the LDS holds (512 B static)
+  const long per_cu = std::max<long>(1, std::min<long>(12, (long)(160 * 1024 / (lds + 512))));
   const long slots = std::min<long>(ncell, per_cu * h->cu_count);
   const long chunk_cells = std::max<long>(slots, std::min<long>(ncell, (long)(8e9 / (8.0 * h->dn.nR)))); // <= 8 GB of rates
   h->ensure_workspace(slots, chunk_cells);

@@ -17,7 +17,8 @@
 namespace racgpu {
 
 struct CellCtx {
-  double *y, *savf, *acor, *ewt, *wx;                          // LDS, nS doubles each
+  double *y, *savf, *wx;                                       // LDS, nS doubles each: iterate, f(y), linear-solver work vector
+  double *acor, *ewt;                                          // HBM, npad each: accumulated correction, inverse error weights (elementwise use only)
   double *yh, *Pv, *Lv, *Uv, *Dinv, *rates, *rtol, *atol;      // this cell's HBM slices
   int lane, n, npad;
   int *marker;    // developer aid: host-visible progress word, or null
@@ -60,7 +61,12 @@ constexpr int kMaxord = 5, kMaxcor = 3, kMsbp = 20, kMxncf = 10, kMsbj = 50;
 template <typename V>
 RG_DEV double dev_vnorm(const CellCtx &c, V v) { // DVNORM over NEQ = nS+1 entries, the T entry being zero
   double s = 0.0;
-  for (int i = c.lane; i < c.n; i += 64) { const double q = v(i) * c.ewt[i]; s += q * q; }
+  const rsrc_t bE = mkbuf(c.ewt);
+  for (int i0 = 0; i0 < c.n; i0 += 64) {
+    const double e = bload_f64(bE, c.lane * 8, i0 * 8);
+    const int i = i0 + c.lane;
+    if (i < c.n) { const double q = v(i) * e; s += q * q; }
+  }
   return sqrt(wave_sum(s) * g_wc.inv_neq);
 }
 
@@ -163,7 +169,7 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
 // expression keeps the reference's operand order.
 RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s) {
   const int n = c.n, lane = c.lane, l8 = c.lane * 8;
-  const rsrc_t bY = mkbuf(c.yh);
+  const rsrc_t bY = mkbuf(c.yh), bA = mkbuf(c.acor), bE = mkbuf(c.ewt);
   const double told = s.tn;
   double delp = 0.0, del = 0.0, dsm = 0.0, rh = 0.0;
   int ncf = 0, m = 0, iredo = 0;
@@ -198,13 +204,13 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         s.ipup = 0; s.rc = 1.0; s.nslp = s.nst; s.crate = 0.7;
         if (s.ierpj != 0) break;
       }
-      for (int i = lane; i < n; i += 64) c.acor[i] = 0.0;
+      for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bA, l8, i0 * 8, 0.0);
       bool fail410 = false;
       for (;;) {
         for (int i0 = 0; i0 < n; i0 += 64) {
-          const double y1 = bload_f64(bY, l8, col_off(c, 1) + i0 * 8);
+          const double y1 = bload_f64(bY, l8, col_off(c, 1) + i0 * 8), ac = bload_f64(bA, l8, i0 * 8);
           const int i = i0 + lane;
-          if (i < n) c.y[i] = s.h * c.savf[i] - (y1 + c.acor[i]);
+          if (i < n) c.y[i] = s.h * c.savf[i] - (y1 + ac);
         }
         dev_mark(c, 2400 + m);
         { const long long t0 = dev_clock(); dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane); cyc_add(CYC_SOLVE, dev_clock() - t0); }
@@ -212,9 +218,9 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         del = dev_vnorm(c, [&](int i) { return c.y[i]; });
         const double el1 = P.elco[s.nq][1];
         for (int i0 = 0; i0 < n; i0 += 64) {
-          const double y0 = bload_f64(bY, l8, i0 * 8);
+          const double y0 = bload_f64(bY, l8, i0 * 8), ac = bload_f64(bA, l8, i0 * 8);
           const int i = i0 + lane;
-          if (i < n) { const double a = c.acor[i] + c.y[i]; c.acor[i] = a; c.y[i] = y0 + el1 * a; }
+          if (i < n) { const double a = ac + c.y[i]; bstore_f64(bA, l8, i0 * 8, a); c.y[i] = y0 + el1 * a; }
         }
         if (m != 0) s.crate = fmax(0.2 * s.crate, del / delp);
         const double dcon = del * fmin(1.0, 1.5 * s.crate) / (P.tesco[s.nq][2] * s.conit);
@@ -242,7 +248,14 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     // label 450: local error test
     s.jcur = 0;
     if (m == 0) dsm = del / P.tesco[s.nq][2];
-    else dsm = dev_vnorm(c, [&](int i) { return c.acor[i]; }) / P.tesco[s.nq][2];
+    else {
+      double q = 0.0;
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const double w = bload_f64(bA, l8, i0 * 8) * bload_f64(bE, l8, i0 * 8);
+        if (i0 + lane < n) q += w * w;
+      }
+      dsm = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][2];
+    }
 
     bool consider = false;
     double rhup = 0.0;
@@ -265,9 +278,8 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       iredo = 2; rhup = 0.0; consider = true;
     } else {
       s.kflag = 0; iredo = 0; s.nst++; s.hu = s.h; s.nqu = s.nq; s.qsum += s.nq;
-      for (int i0 = 0; i0 < n; i0 += 64) { // element-outer: acor is read from LDS once per block
-        const int i = i0 + lane;
-        const double ac = i < n ? c.acor[i] : 0.0;
+      for (int i0 = 0; i0 < n; i0 += 64) { // element-outer: acor is read once per block
+        const double ac = bload_f64(bA, l8, i0 * 8);
         for (int j = 1; j <= s.l; ++j) {
           const int o = col_off(c, j - 1) + i0 * 8;
           bstore_f64(bY, l8, o, bload_f64(bY, l8, o) + P.elco[s.nq][j] * ac);
@@ -280,7 +292,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
           for (int i0 = 0; i0 < n; i0 += 64) {
             const double top = bload_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8);
             const int i = i0 + lane;
-            if (i < n) c.savf[i] = c.acor[i] - top;
+            if (i < n) c.savf[i] = bload_f64(bA, l8, i0 * 8) - top;
           }
           const double dup = dev_vnorm(c, [&](int i) { return c.savf[i]; }) / P.tesco[s.nq][3];
           const double exup = 1.0 / (s.l + 1);
@@ -289,7 +301,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         consider = true;
       } else {
         if (s.ialth <= 1 && s.l != s.lmax) {
-          for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8, c.acor[i]); }
+          for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8, bload_f64(bA, l8, i0 * 8));
         }
         goto done700;
       }
@@ -302,9 +314,8 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       if (s.nq != 1) {
         double q = 0.0;
         for (int i0 = 0; i0 < n; i0 += 64) {
-          const double last = bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8);
-          const int i = i0 + lane;
-          if (i < n) { const double w = last * c.ewt[i]; q += w * w; }
+          const double w = bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8) * bload_f64(bE, l8, i0 * 8);
+          if (i0 + lane < n) q += w * w;
         }
         const double ddn = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][1];
         const double exdn = 1.0 / s.nq;
@@ -317,7 +328,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         newq = s.l; rh = rhup;
         if (rh < 1.1) { s.ialth = 3; goto done700; }
         const double r = P.elco[s.nq][s.l] / s.l;
-        for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, newq) + i0 * 8, c.acor[i] * r); }
+        for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bY, l8, col_off(c, newq) + i0 * 8, bload_f64(bA, l8, i0 * 8) * r);
       } else {
         if (sel == 0) { newq = s.nq; rh = rhsm; }
         else { newq = s.nq - 1; rh = rhdn; if (s.kflag < 0 && rh > 1.0) rh = 1.0; }
@@ -336,7 +347,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
 
 done700: {
     const double r = 1.0 / P.tesco[s.nqu][2];
-    for (int i = lane; i < n; i += 64) c.acor[i] = c.acor[i] * r;
+    for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bA, l8, i0 * 8, bload_f64(bA, l8, i0 * 8) * r);
   }
   s.hold = s.h; s.jstart = 1;
   return s.kflag;
@@ -355,11 +366,12 @@ RG_DEV void dev_intdy0(const CellCtx &c, const Lsodes &s, double t) { // y <- in
 
 RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some weight is <= 0
   bool bad = false;
-  const rsrc_t bY = mkbuf(c.yh), bR = mkbuf(c.rtol), bA = mkbuf(c.atol);
+  const rsrc_t bY = mkbuf(c.yh), bR = mkbuf(c.rtol), bA = mkbuf(c.atol), bE = mkbuf(c.ewt);
   const int l8 = c.lane * 8;
   for (int i0 = 0; i0 < c.n; i0 += 64) {
     const double e = bload_f64(bR, l8, i0 * 8) * fabs(bload_f64(bY, l8, i0 * 8)) + bload_f64(bA, l8, i0 * 8);
-    if (i0 + c.lane < c.n) { if (e <= 0.0) bad = true; c.ewt[i0 + c.lane] = 1.0 / e; }
+    if (i0 + c.lane < c.n && e <= 0.0) bad = true;
+    bstore_f64(bE, l8, i0 * 8, 1.0 / e);
   }
   const double Tg = g_wc.Tgas, eT = g_wc.rT * fabs(Tg) + g_wc.aT;
   if (eT <= 0.0) bad = true;
@@ -376,7 +388,7 @@ RG_DEV void dev_finish(const CellCtx &c, const Lsodes &s, double &t) { // label 
 RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s, double &t, double tout, int &istate) {
   const double u = kUround;
   const int n = c.n, lane = c.lane, l8 = c.lane * 8;
-  const rsrc_t bY = mkbuf(c.yh);
+  const rsrc_t bY = mkbuf(c.yh), bE = mkbuf(c.ewt);
   if (istate != 1 && s.init == 0) { istate = -3; return; }
   if (istate == 1) { s.init = 0; if (tout == t) return; }
   if (istate == 3) {
@@ -450,9 +462,8 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
     {
       double q = 0.0;
       for (int i0 = 0; i0 < n; i0 += 64) {
-        const double y0 = bload_f64(bY, l8, i0 * 8);
-        const int i = i0 + lane;
-        if (i < n) { const double v = y0 * c.ewt[i]; q += v * v; }
+        const double v = bload_f64(bY, l8, i0 * 8) * bload_f64(bE, l8, i0 * 8);
+        if (i0 + lane < n) q += v * v;
       }
       const double Tg = g_wc.Tgas, vT = Tg / (g_wc.rT * fabs(Tg) + g_wc.aT);
       const double tolsf = u * sqrt((wave_sum(q) + vT * vT) * g_wc.inv_neq);
@@ -475,7 +486,14 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
       istate = (kflag == -1) ? -4 : -5;
       // IMXER: first index of the largest |acor*ewt| (label 560)
       double big = -1.0; int idx = 0x7fffffff;
-      for (int i = lane; i < n; i += 64) { const double sz = fabs(c.acor[i] * c.ewt[i]); if (sz > big) { big = sz; idx = i; } }
+      {
+        const rsrc_t bA = mkbuf(c.acor);
+        for (int i0 = 0; i0 < n; i0 += 64) {
+          const double sz = fabs(bload_f64(bA, l8, i0 * 8) * bload_f64(bE, l8, i0 * 8));
+          const int i = i0 + lane;
+          if (i < n && sz > big) { big = sz; idx = i; }
+        }
+      }
 #pragma unroll
       for (int mm = 32; mm >= 1; mm >>= 1) {
         const double ob = __shfl_xor(big, mm, 64); const int oi = __shfl_xor(idx, mm, 64);

@@ -1,8 +1,9 @@
 """Cell-sweep sharding: the caller-side partition of a grid of cells over the GPUs of one node.
 
 Cells are independent initial-value problems once their input records are frozen,
-so a sweep is a static block partition plus ONE gather of the end-state abundances (RCCL over xGMI when
-the process group is "nccl"; "gloo" in the CPU tests).  No other collective is on the path.
+so a sweep is a static partition plus ONE gather of the results -- end-state abundances, t_final, quality and the
+per-cell counters travel together in one block per rank (RCCL over xGMI when the process group is "nccl";
+"gloo" in the CPU tests).  No other collective is on the path.
 Reference seam: the serial loop over cells in do_chemical_stuff, reference src/disk.f90:864-938.
 """
 import numpy as np
@@ -15,34 +16,53 @@ def partition(ncell, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def interleaved_order(cost):
-    """Permutation that deals cells round-robin by descending expected cost (e.g. n_gas), so that contiguous
-    blocks of the permuted list carry similar work (steps per cell vary 2-3x with density and temperature)."""
-    return np.argsort(-np.asarray(cost), kind="stable")
+def interleaved_order(cost, world):
+    """Permutation that deals the cells round-robin over ``world`` ranks by descending expected cost (e.g. n_gas, or the
+    step count of the previous global iteration): after it, the contiguous blocks of ``partition`` hold cells
+    k, k + world, k + 2 world, ... of the cost ranking, so every rank gets the same mix of expensive and cheap cells
+    (steps per cell vary 2-3x with density and temperature, a few cells by 10x)."""
+    idx = np.argsort(-np.asarray(cost, dtype=np.float64), kind="stable")
+    return np.concatenate([idx[r::world] for r in range(world)])
 
 
-def solve_sharded(solve_local, cells, y, dist=None, device=None):
-    """Solve rows [lo, hi) of (cells, y) with ``solve_local(cells_block, y_block) -> y_end_block`` and gather.
+def solve_sharded(solve_local, cells, y, dist=None, device=None, cost=None):
+    """Solve the cells of this rank with ``solve_local(cells_block, y_block) -> dict(y, t_final, quality, stats)`` and gather.
 
-    ``dist`` is torch.distributed (initialised) or None for a single process.  Returns the full
-    [ncell, nSpecies] end-state array on every rank, in the original cell order."""
+    ``dist`` is torch.distributed (initialised) or None for a single process.  ``cost`` (optional, [ncell]) balances
+    the ranks through ``interleaved_order``; without it the partition is contiguous in the caller's cell order.
+    Returns dict(y [ncell, nS], t_final [ncell], quality [ncell] int32, stats [ncell, NSTAT] int64) on every rank, in the
+    original cell order."""
     import torch
     ncell = cells.shape[0]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return solve_local(cells, y)
+        out = solve_local(cells, y)
+        return dict(y=np.asarray(out["y"]), t_final=np.asarray(out["t_final"]), quality=np.asarray(out["quality"], np.int32),
+                    stats=np.asarray(out["stats"], np.int64))
     world, rank = dist.get_world_size(), dist.get_rank()
+    order = interleaved_order(cost, world) if cost is not None else np.arange(ncell)
     lo, hi = partition(ncell, world, rank)
-    y_loc = solve_local(cells[lo:hi], y[lo:hi])
+    mine = order[lo:hi]
+    res = solve_local(np.ascontiguousarray(cells[mine]), np.ascontiguousarray(y[mine]))
     nS = y.shape[1]
+    st = np.asarray(res["stats"], np.int64).reshape(hi - lo, -1)
+    nstat = st.shape[1]
+    ncol = nS + 2 + nstat
     maxn = -(-ncell // world)
-    t_loc = torch.zeros((maxn, nS), dtype=torch.float64, device=device)
-    t_loc[:hi - lo] = torch.as_tensor(np.ascontiguousarray(y_loc), dtype=torch.float64, device=device)
-    out = torch.empty((world * maxn, nS), dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(out, t_loc) if hasattr(dist, "all_gather_into_tensor") and device is not None else \
-        dist.all_gather(list(out.view(world, maxn, nS).unbind(0)), t_loc)
-    out = out.view(world, maxn, nS).cpu().numpy()
-    full = np.empty((ncell, nS))
+    blk = np.zeros((maxn, ncol))
+    blk[:hi - lo, :nS] = res["y"]
+    blk[:hi - lo, nS] = res["t_final"]
+    blk[:hi - lo, nS + 1] = res["quality"]
+    blk[:hi - lo, nS + 2:] = st  # counters stay far below 2^53: exact in f64
+    t_loc = torch.as_tensor(blk, dtype=torch.float64, device=device)
+    out = torch.empty((world * maxn, ncol), dtype=torch.float64, device=device)
+    if hasattr(dist, "all_gather_into_tensor") and device is not None:
+        dist.all_gather_into_tensor(out, t_loc)
+    else:
+        dist.all_gather(list(out.view(world, maxn, ncol).unbind(0)), t_loc)
+    out = out.view(world, maxn, ncol).cpu().numpy()
+    full = np.empty((ncell, ncol))
     for r in range(world):
         a, b = partition(ncell, world, r)
-        full[a:b] = out[r, :b - a]
-    return full
+        full[order[a:b]] = out[r, :b - a]
+    return dict(y=np.ascontiguousarray(full[:, :nS]), t_final=full[:, nS].copy(), quality=full[:, nS + 1].astype(np.int32),
+                stats=np.rint(full[:, nS + 2:]).astype(np.int64))

@@ -1,0 +1,43 @@
+"""Build-time guard (CPU only; hipcc cross-compiles gfx950 without a GPU): the register, scratch and LDS use of the hot kernel.
+
+Round 1 lost a GPU run to a build of k_solve that spilled VGPRs to scratch ("Hazards"), and the kernel sat
+at the 256-VGPR edge where one added variable halves the occupancy.  This test compiles rac-2d_amd/csrc/engine.hip with the
+Makefile's own flags plus -Rpass-analysis=kernel-resource-usage and fails when k_solve uses scratch, accumulator registers
+(hipcc's spill space once the 256 architectural VGPRs are exhausted), or more VGPRs than 3 waves per SIMD allow."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_k_solve_has_no_scratch_and_fits_three_waves_per_simd():
+    csrc = os.path.join(ROOT, "rac-2d_amd", "csrc")
+    out = subprocess.run(["make", "-s", "-C", csrc, "resources"], capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    kernels = {}
+    cur = None
+    for line in text.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1); kernels[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)", line)
+        if m and cur:
+            kernels[cur][m.group(1).strip()] = m.group(2)
+    ks = [v for k, v in kernels.items() if "k_solve" in k]
+    assert len(ks) == 1, (list(kernels), text[-2000:])
+    k = ks[0]
+    assert int(k["ScratchSize"]) == 0, k           # never: see the module docstring
+    assert int(k["AGPRs"]) == 0, k                 # AGPR spills mean the 256 VGPRs ran out
+    assert int(k["VGPRs Spill"]) == 0, k
+    assert int(k["VGPRs"]) <= 168, k               # 3 waves per SIMD (MI355X_MICROARCH.md, register files)
+    assert int(k["Occupancy"]) >= 3, k
+    for name, v in kernels.items():                # no kernel of the library may use scratch
+        assert int(v["ScratchSize"]) == 0, (name, v)
