@@ -116,6 +116,14 @@ void racgpu_network_destroy(racgpu_network *);
 /* nnzJ: species-block Jacobian pattern actually used (dead reactions and the T row/column dropped);
  * nzl/nzu: strict lower/upper fill of its LU.  Any pointer may be NULL. */
 int racgpu_network_dims(const racgpu_network *, int32_t *nSpecies, int32_t *nReactions, int32_t *nnzJ, int32_t *nzl, int32_t *nzu);
+/* LENRW = IWORK(17) of the reference's DLSODES for this network (the RWORK length it reports as needed).  Used for one
+ * reference behaviour only: after an error return the reference re-enters DLSODES with ISTATE = 3, whose sparse-matrix
+ * preprocessing zeroes NNZ words at the end of a temporary work area (src/opkda1.f:1487-1494); with the RWORK the reference
+ * allocates (20 + 4 NNZ + 28 NEQ, src/chemistry.f90:1945) that area overlaps the tail of the saved Newton matrix, so the next
+ * step starts from a partly zeroed P.  The engine reproduces it when it knows LENRW (built in for the four networks in data/;
+ * the value depends on YSMP's compressed index storage and cannot be derived without it); 0 = unknown: the saved P survives. */
+int racgpu_network_set_reference_lenrw(racgpu_network *, int32_t lenrw);
+int racgpu_network_reference_lenrw(const racgpu_network *);
 int racgpu_species_name(const racgpu_network *, int32_t i, char *buf, int32_t buflen); /* chem_species%names(i) */
 int racgpu_species_index(const racgpu_network *, const char *name);                   /* 0 if absent */
 /* reaction table as parsed: reac[nR*3], prod[nR*4] (1-based, 0 = empty), n_reac, n_prod, itype, n_dupli[nR]; any may be NULL */

@@ -58,7 +58,14 @@ typedef struct { /* the chemsol_params namelist scalars that the path reads */
   double Diff2DesorRatio, special_gH_E_diff;
   int use_special_gH_mobi, update_gH_params_realtime;
   double max_runtime_allowed; /* seconds of MODELLED reference CPU time for the guards of :480-491; <= 0 = off */
+  double rt_cost_f, rt_cost_jac, rt_cost_lu; /* modelled seconds per f call / full Jacobian / factorisation */
 } orc_params;
+
+/* one local iteration of calc_this_cell's loop (src/disk.f90:1651-1791) as orc_calc_cell ran it */
+typedef struct {
+  double t0, dt_first, t_end /* touts(n_record_real) */, t_final /* after this iteration */, n_mol_on_grain;
+  int n_record, quality /* of the cell after this iteration */, nerr, isav, proceeds;
+} orc_iter_info;
 
 typedef struct { long nst, nfe, nje, nlu; int nnz, nzl, nzu; long nst_last, nfe_last, nje_last, nlu_last; } orc_stats;
 
@@ -94,6 +101,13 @@ int orc_evol_solve(const orc_network *, const orc_params *, const double *cell, 
 /* calc_this_cell-style convenience: y0 -> Grain0 slot, T slot, tolerances(j=1), rates, solve. */
 int orc_solve_cell(const orc_network *, const orc_params *, const double *cell, const double *y0,
                    double *y_out, double *t_final, int *quality, int *nerr, orc_stats *stats);
+/* rectify_abundances, src/chemistry.f90:2170-2201 */
+void orc_rectify_abundances(const orc_network *, double *y /* [nS] */);
+/* The local-iteration loop of calc_this_cell (src/disk.f90:1651-1791) with set_initial_condition_4solver_continue
+ * (src/disk.f90:2103-2146): y_init [nS] = abundances at t = 0 (Grain0 slot already set); abund_out [nS]; info [nlocal_iter].
+ * Returns the number of iterations run (>= 1), or < 0 on a fatal path. */
+int orc_calc_cell(const orc_network *, const orc_params *, const double *cell, const double *y_init, int nlocal_iter,
+                  double *abund_out, double *t_final, int *quality, orc_iter_info *info, orc_stats *stats);
 #ifdef __cplusplus
 }
 #endif

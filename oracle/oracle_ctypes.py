@@ -44,6 +44,7 @@ class Params(C.Structure):
         ("Diff2DesorRatio", C.c_double), ("special_gH_E_diff", C.c_double),
         ("use_special_gH_mobi", C.c_int), ("update_gH_params_realtime", C.c_int),
         ("max_runtime_allowed", C.c_double),
+        ("rt_cost_f", C.c_double), ("rt_cost_jac", C.c_double), ("rt_cost_lu", C.c_double),
     ]
 
 
@@ -51,6 +52,12 @@ class Stats(C.Structure):
     _fields_ = [("nst", C.c_long), ("nfe", C.c_long), ("nje", C.c_long), ("nlu", C.c_long),
                 ("nnz", C.c_int), ("nzl", C.c_int), ("nzu", C.c_int),
                 ("nst_last", C.c_long), ("nfe_last", C.c_long), ("nje_last", C.c_long), ("nlu_last", C.c_long)]
+
+
+class IterInfo(C.Structure):
+    _fields_ = [("t0", C.c_double), ("dt_first", C.c_double), ("t_end", C.c_double), ("t_final", C.c_double),
+                ("n_mol_on_grain", C.c_double), ("n_record", C.c_int), ("quality", C.c_int), ("nerr", C.c_int),
+                ("isav", C.c_int), ("proceeds", C.c_int)]
 
 
 _lib = None
@@ -158,19 +165,41 @@ class Network:
         y[self.nS] = cell[0]
         return y
 
-    def solve_cell(self, params, cell, y0, record=False):
-        """calc_this_cell-style solve of one cell; returns dict."""
+    def calc_cell(self, params, cell, y0, nlocal_iter=4, y_init=None):
+        """The local-iteration loop of calc_this_cell (reference src/disk.f90:1651-1791) for one cell.  y_init [nS] overrides
+        the initial abundances (default: y0 with the Grain0 slot set)."""
+        cell = np.ascontiguousarray(cell, dtype=np.float64)
+        yi = self.initial_state(y0, cell)[:self.nS].copy() if y_init is None else np.ascontiguousarray(y_init, dtype=np.float64)
+        ab = np.zeros(self.nS)
+        tf = C.c_double(); q = C.c_int(); st = Stats()
+        info = (IterInfo * nlocal_iter)()
+        n = lib().orc_calc_cell(self._p, C.byref(params), _dp(cell), _dp(yi), C.c_int(nlocal_iter), _dp(ab), C.byref(tf), C.byref(q), info, C.byref(st))
+        iters = [dict(t0=i.t0, dt_first=i.dt_first, t_end=i.t_end, t_final=i.t_final, n_mol_on_grain=i.n_mol_on_grain, n_record=i.n_record,
+                      quality=i.quality, nerr=i.nerr, isav=i.isav, proceeds=i.proceeds) for i in info[:max(n, 0)]]
+        return dict(rc=n, y=ab, t_final=tf.value, quality=q.value, iters=iters, nst=st.nst, nfe=st.nfe, nje=st.nje, nlu=st.nlu)
+
+    def solve_cell(self, params, cell, y0, record=False, j=1, y_init=None, t0=0.0, rectify=False):
+        """One chem_evol_solve run of one cell (tolerance policy j, start time t0 with the caller's continue rule for the first
+        step, optional rectify_abundances); returns dict."""
         cell = np.ascontiguousarray(cell, dtype=np.float64)
         y = self.initial_state(y0, cell)
+        if y_init is not None:
+            y[:self.nS] = y_init
+        if rectify:
+            lib().orc_rectify_abundances(self._p, _dp(y))
         t_max = cell[27] if cell[27] > 0 else params.t_max
-        rtol, atol = self.tolerances(params, 1, cell[6])
+        if t0 > 0.0:
+            pp = Params(); C.memmove(C.byref(pp), C.byref(params), C.sizeof(Params))
+            pp.dt_first_step = max(params.dt_first_step, 1e-3 * t0)
+            params = pp
+        rtol, atol = self.tolerances(params, j, cell[6])
         rates = self.rates(params, cell)
-        nrec = lib().orc_n_record(C.byref(params), 0.0, t_max)
+        nrec = lib().orc_n_record(C.byref(params), t0, t_max)
         rec = np.zeros((nrec, self.NEQ)) if record else None
         touts = np.zeros(nrec)
         tf = C.c_double(); q = C.c_int(); ne = C.c_int(); nrr = C.c_int(); st = Stats()
         rc = lib().orc_evol_solve(self._p, C.byref(params), _dp(cell), _dp(rates), _dp(rtol), _dp(atol), _dp(y),
-                                  C.c_double(0.0), C.c_double(t_max), C.byref(tf), C.byref(q), C.byref(ne),
+                                  C.c_double(t0), C.c_double(t_max), C.byref(tf), C.byref(q), C.byref(ne),
                                   C.byref(nrr), _dp(rec) if record else None, _dp(touts), C.byref(st))
         return dict(rc=rc, y=y, t_final=tf.value, quality=q.value, nerr=ne.value, n_record_real=nrr.value,
                     record=rec, touts=touts, nst=st.nst, nfe=st.nfe, nje=st.nje, nlu=st.nlu,

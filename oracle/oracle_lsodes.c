@@ -316,6 +316,18 @@ void orc_lsodes_call(orc_lsodes *s, double *y, double *t, double tout, int *ista
        * LREQ+1-NNZ (:1511), where the previous P still sits because the layout is the same as before; so the
        * saved P survives an ISTATE=3 call and DPRJS may legitimately rescale it (JOK = 1). */
       s->jstart = -1;
+      /* ... except where the temporary area overlaps it: the zeroed words are RWORK(LRW - NCOLM*N - NNZ + 1 .. LRW - NCOLM*N)
+       * (LENWK = LRW - 20 - NCOLM*N at this point, src/opkdmain.f:3185-3196, NCOLM = min(NQ+1, MAXORD+2)), the saved P is
+       * RWORK(20 + LREQ - NNZ + 1 .. 20 + LREQ) with LREQ = LENRW - 20 - 9 N; with the LRW the reference allocates
+       * (20 + 4 NNZ0 + 28 N, src/chemistry.f90:1945) the last Z = 20 + LREQ - (LRW - NCOLM*N - NNZ) entries of P are zeroed.
+       * Checked against the reference: with it the output times of an mxstep = 6 run agree to 7 digits over the first
+       * intervals, without it they are off by factors from the first ISTATE = 3 call on (tests/golden/policy_grain.npz). */
+      if (s->lenrw_ref > 0) {
+        const long nnz = s->S->nnz, ncolm = (s->nq + 1 < 7) ? s->nq + 1 : 7;
+        long Z = 20 + (s->lenrw_ref - 20 - 9L * n) - (s->lrw_ref - ncolm * n - nnz);
+        if (Z > nnz) Z = nnz;
+        for (long k = nnz - Z; k < nnz; k++) if (k >= 0) s->P[k] = 0.0;
+      }
     }
   }
   if (*istate == 1) { /* Block C */

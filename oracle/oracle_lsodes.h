@@ -8,6 +8,7 @@ typedef struct {
   int n; const orc_symbolic *S; orc_f_fn f; orc_jac_fn jac; void *ctx;
   const double *rtol, *atol;         /* [n], owned by caller; may change between calls (ISTATE=3) */
   double tcrit, hmax; int mxstep;    /* RWORK(1), RWORK(6), IWORK(6) */
+  long lrw_ref, lenrw_ref;           /* the reference's RWORK length and DLSODES' IWORK(17) (0: unknown, P survives ISTATE=3) */
   double *yh, *ewt, *savf, *acor, *P, *L, *U, *Dinv, *w, *z;
   /* COMMON /DLS001/ */
   double conit, crate, el[14], elco[6][14], hold, rmax, tesco[6][4], ccmax, el0, h, hmin, hmxi, hu, rc, tn, uround;

@@ -250,6 +250,7 @@ void orc_params_default(orc_params *p) { /* type defaults src/chemistry.f90:107-
   p->mxstep_per_interval = 6000; p->steps_reset_solver = 50; p->H2_form_use_moeq = 0;
   p->Diff2DesorRatio = 0.5; p->special_gH_E_diff = 225.0; p->use_special_gH_mobi = 0;
   p->update_gH_params_realtime = 0; p->max_runtime_allowed = 60.0;
+  p->rt_cost_f = 47e-6; p->rt_cost_jac = 10.4e-3; p->rt_cost_lu = 1.0e-3;
 }
 
 int orc_n_record(const orc_params *p, double t0, double t_max) { /* :1894-1899 */

@@ -38,11 +38,19 @@ int orc_evol_solve(const orc_network *net, const orc_params *p, const double *ce
                    double *rtol, double *atol, double *y, double t0, double t_max,
                    double *t_final, int *quality, int *nerr_out, int *n_record_real,
                    double *record, double *touts, orc_stats *st) {
+  /* p->dt_first_step is chemsol_params%dt_first_step of THIS run (the caller's continue rule has been applied to it) */
   const int NEQ = net->NEQ;
   const orc_symbolic *S = symbolic_for(net);
   cb_ctx ctx = {net, p, cell, rates, S};
   orc_lsodes *s = orc_lsodes_create(NEQ, S, cb_f, cb_jac, &ctx);
   s->rtol = rtol; s->atol = atol; s->tcrit = t_max; s->hmax = t_max; s->mxstep = p->mxstep_per_interval;
+  s->lrw_ref = 20 + 4L * net->NNZ + 28L * NEQ; /* chem_prepare_solver_storage, src/chemistry.f90:1945 */
+  {
+    /* IWORK(17) as the reference's DLSODES reports it (ref_driver section '# workspace'); YSMP-dependent, known for the shipped networks */
+    static const struct { int nS, nR; long lenrw; } known[] = {{464, 4767, 59430}, {467, 4801, 60324}, {484, 5830, 65578}, {524, 6425, 82134}};
+    s->lenrw_ref = 0;
+    for (unsigned k = 0; k < sizeof known / sizeof known[0]; k++) if (known[k].nS == net->nS && known[k].nR == net->nR) s->lenrw_ref = known[k].lenrw;
+  }
   int n_record = orc_n_record(p, t0, t_max);
   int istate = 1, nerr = 0, nerr_c = 0, qual = 0, nrr = 1, ret = 0;
   double t = t0, t_step = p->dt_first_step, tout = t + t_step;
@@ -57,7 +65,7 @@ int orc_evol_solve(const orc_network *net, const orc_params *p, const double *ce
     long nst0 = was_restart ? 0 : s->nst, nfe0 = was_restart ? 0 : s->nfe, nje0 = was_restart ? 0 : s->nje, nlu0 = was_restart ? 0 : s->nlu;
     orc_lsodes_call(s, y, &t, tout, &istate);
     acc.nst += s->nst - nst0; acc.nfe += s->nfe - nfe0; acc.nje += s->nje - nje0; acc.nlu += s->nlu - nlu0;
-    const double rt_this = 47e-6 * (double)(s->nfe - nfe0) + 10.4e-3 * (double)(s->nje - nje0) + 1.0e-3 * (double)(s->nlu - nlu0);
+    const double rt_this = p->rt_cost_f * (double)(s->nfe - nfe0) + p->rt_cost_jac * (double)(s->nje - nje0) + p->rt_cost_lu * (double)(s->nlu - nlu0);
     rt_total += rt_this;
     if (touts) touts[i - 1] = t;
     if (record) memcpy(record + (size_t)(i - 1) * NEQ, y, (size_t)NEQ * sizeof(double));
@@ -121,4 +129,73 @@ int orc_solve_cell(const orc_network *net, const orc_params *p, const double *ce
   if (rc == 0) rc = orc_evol_solve(net, p, cell, rates, rtol, atol, y_out, 0.0, t_max, t_final, quality, nerr, NULL, NULL, NULL, stats);
   free(rates); free(rtol); free(atol);
   return rc;
+}
+
+void orc_rectify_abundances(const orc_network *net, double *y) { /* src/chemistry.f90:2192-2194 */
+  double q = 0.0;
+  for (int i = 0; i < net->nS; i++) q += y[i] * (double)net->elements[i * ORC_NELEM + 0];
+  y[net->idx10[2] - 1] = y[net->idx10[2] - 1] + q;
+}
+
+int orc_calc_cell(const orc_network *net, const orc_params *p0, const double *cell, const double *y_init, int nlocal_iter,
+                  double *abund_out, double *t_final_out, int *quality_out, orc_iter_info *info, orc_stats *stats) {
+  const int NEQ = net->NEQ, nS = net->nS;
+  double *rates = malloc((size_t)net->nR * sizeof(double));
+  double *rtol = malloc((size_t)NEQ * sizeof(double)), *atol = malloc((size_t)NEQ * sizeof(double));
+  double *y = malloc((size_t)NEQ * sizeof(double)), *abund = malloc((size_t)nS * sizeof(double));
+  const double t_max = cell[ORC_P_TMAX] > 0.0 ? cell[ORC_P_TMAX] : p0->t_max;
+  double t_final = 0.0;
+  int qual_cell = 0, niter = 0, rc = 0;
+  orc_stats acc; memset(&acc, 0, sizeof acc);
+  memcpy(abund, y_init, (size_t)nS * sizeof(double));
+  for (int j = 1; j <= nlocal_iter; j++) {
+    orc_params p = *p0;
+    const double t0 = (j > 1) ? t_final : 0.0;
+    memcpy(y, abund, (size_t)nS * sizeof(double));
+    y[nS] = cell[ORC_P_TGAS];
+    if (j > 1) { /* set_initial_condition_4solver_continue, src/disk.f90:2121-2130 */
+      orc_rectify_abundances(net, y);
+      p.dt_first_step = fmax(p0->dt_first_step, t0 * 1e-3);
+    }
+    const int n_record = orc_n_record(&p, t0, t_max);
+    double *record = malloc((size_t)n_record * NEQ * sizeof(double)), *touts = malloc((size_t)n_record * sizeof(double));
+    orc_set_tolerances(net, &p, j, cell[ORC_P_D2H], rtol, atol);
+    rc = orc_cal_rates(net, &p, cell, rates, NULL);
+    double t_end = t0; int q = 0, nerr = 0, nrr = 1; orc_stats st;
+    if (rc == 0) rc = orc_evol_solve(net, &p, cell, rates, rtol, atol, y, t0, t_max, &t_end, &q, &nerr, &nrr, record, touts, &st);
+    if (rc != 0) { free(record); free(touts); break; }
+    acc.nst += st.nst; acc.nfe += st.nfe; acc.nje += st.nje; acc.nlu += st.nlu; acc.nnz = st.nnz; acc.nzl = st.nzl; acc.nzu = st.nzu;
+    niter = j;
+    orc_iter_info *I = info ? &info[j - 1] : NULL;
+    if (I) { I->t0 = t0; I->dt_first = p.dt_first_step; I->n_record = n_record; I->t_end = touts[nrr - 1]; I->nerr = nerr; }
+    if (j > 1 && touts[nrr - 1] <= t_final) { /* "Local iteration does not proceed" (src/disk.f90:1706-1714) */
+      if (I) { I->quality = qual_cell; I->isav = 0; I->t_final = t_final; I->proceeds = 0; I->n_mol_on_grain = NAN; }
+      free(record); free(touts);
+      break;
+    }
+    int isav;
+    for (isav = nrr; isav >= 1; isav--) { /* src/disk.f90:1716-1721 */
+      const double *r = record + (size_t)(isav - 1) * NEQ;
+      if (!isnan(r[nS]) && !(net->idx10[0] > 0 && isnan(r[net->idx10[0] - 1]))) break;
+    }
+    qual_cell = q;
+    double nmol = NAN;
+    if (isav > 1) {
+      memcpy(abund, record + (size_t)(isav - 1) * NEQ, (size_t)nS * sizeof(double));
+      t_final = touts[isav - 1];
+      nmol = 0.0; /* get_ice_coverage's side effect, src/chemistry.f90:995-1001 */
+      for (int g = 0; g < net->nGrain; g++) nmol += abund[net->idxGrain[g] - 1];
+      nmol = nmol / cell[ORC_P_D2H];
+    }
+    if (I) { I->quality = qual_cell; I->isav = isav; I->t_final = t_final; I->proceeds = 1; I->n_mol_on_grain = nmol; }
+    free(record); free(touts);
+    if (isav <= 1) break; /* "No useful data produced!" */
+    if (qual_cell == 0 || t_final >= 0.5 * t_max) break;
+  }
+  memcpy(abund_out, abund, (size_t)nS * sizeof(double));
+  if (t_final_out) *t_final_out = t_final;
+  if (quality_out) *quality_out = qual_cell;
+  if (stats) *stats = acc;
+  free(rates); free(rtol); free(atol); free(y); free(abund);
+  return rc != 0 ? rc : niter;
 }

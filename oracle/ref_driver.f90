@@ -17,10 +17,18 @@ program ref_driver
   character(len=256) :: nml_file, chem_dir, network, initial, out_dir, cell_file
   integer :: ncell, mxstep, steps_reset, dump_jac, dump_record_every, solve
   double precision :: rtol, atol, dt_first_step, ratio_tstep, t_max
-  logical :: h2_moeq
+  logical :: h2_moeq, special_gH_mobi
+  ! nlocal_iter > 1: the local-iteration loop of calc_this_cell (src/disk.f90:1651-1791) around chem_evol_solve;
+  ! tol_j: j of chem_set_solver_flags_alt for a single pass; y_override: file of rows "cell species value" applied to
+  ! the initial condition (to provoke the sanity exits of src/chemistry.f90:520-530)
+  integer :: nlocal_iter, tol_j
+  character(len=256) :: y_override
   namelist /ref_run/ chem_dir, network, initial, out_dir, cell_file, ncell, &
     rtol, atol, dt_first_step, ratio_tstep, t_max, mxstep, steps_reset, h2_moeq, &
-    dump_jac, dump_record_every, solve
+    dump_jac, dump_record_every, solve, nlocal_iter, tol_j, y_override, special_gH_mobi
+  double precision, allocatable :: abund(:)
+  double precision :: t_final, t_end, dt0, tmp, ov_val
+  integer :: jj, isav, qual_cell, ov_cell, ov_spe, fO, ios
   integer, parameter :: NPAR = 28
   double precision :: cpar(NPAR)
   double precision, allocatable :: ydot(:), pdj(:), dummy(:)
@@ -33,6 +41,7 @@ program ref_driver
   ncell = 1; rtol = 1D-4; atol = 1D-30; dt_first_step = 1D-8; ratio_tstep = 1.1D0
   t_max = 1D6; mxstep = 6000; steps_reset = 50; h2_moeq = .false.
   dump_jac = 1; dump_record_every = 0; solve = 1
+  nlocal_iter = 1; tol_j = 1; y_override = ''; special_gH_mobi = .false.
   open(newunit=fU, file=trim(nml_file), status='old', action='read')
   read(fU, nml=ref_run)
   close(fU)
@@ -53,6 +62,7 @@ program ref_driver
   chemsol_params%H2_form_use_moeq = h2_moeq
   chemsol_params%flag_chem_evol_save = .false.
   chemsol_params%evol_dust_size = .false.
+  chemsol_params%use_special_gH_mobi = special_gH_mobi
   open(newunit=fU, file=trim(out_dir)//'/ref_log.txt', status='replace', action='write')
   chemsol_params%fU_log = fU
 
@@ -69,7 +79,7 @@ program ref_driver
 
   nS = chem_species%nSpecies
   NEQ = chemsol_params%NEQ
-  allocate(ydot(NEQ), pdj(NEQ), dummy(1))
+  allocate(ydot(NEQ), pdj(NEQ), dummy(1), abund(nS))
 
   ! ---- network-level dumps -------------------------------------------------
   open(newunit=fC, file=trim(out_dir)//'/species.txt', status='replace')
@@ -141,6 +151,15 @@ program ref_driver
       chemsol_stor%y(chem_idx_some_spe%i_Grain0) = chem_params%ratioDust2HnucNum
     end if
     chemsol_stor%y(nS + 1) = chem_params%Tgas
+    if (len_trim(y_override) .gt. 0) then
+      open(newunit=fO, file=trim(y_override), status='old', action='read')
+      do
+        read(fO, *, iostat=ios) ov_cell, ov_spe, ov_val
+        if (ios .ne. 0) exit
+        if (ov_cell .eq. ic) chemsol_stor%y(ov_spe) = ov_val
+      end do
+      close(fO)
+    end if
     chemsol_params%evolT = .false.
     chemsol_params%maySwitchT = .false.
     chemsol_params%t0 = 0D0
@@ -149,7 +168,7 @@ program ref_driver
     if (cpar(28) .gt. 0D0) chemsol_params%t_max = cpar(28)
     call chem_evol_solve_prepare_ongoing
     ! src/disk.f90:1671-1686 order: flags, rates, solve.
-    call chem_set_solver_flags_alt(1)
+    call chem_set_solver_flags_alt(tol_j)
     call chem_cal_rates
 
     write(fname, '(A, "/cell_", I4.4, ".txt")') trim(out_dir), ic
@@ -183,7 +202,70 @@ program ref_driver
       end do
     end if
 
-    if (solve .ne. 0) then
+    if ((solve .ne. 0) .and. (nlocal_iter .gt. 1)) then
+      ! calc_this_cell's loop (src/disk.f90:1651-1791) with the continue rule of set_initial_condition_4solver_continue
+      ! (src/disk.f90:2103-2146); every routine called is the reference's own.  One '# iter' section per local iteration:
+      ! j, t0, dt_first_step, n_record, touts(n_record_real), quality, NERR, isav, t_final handed back, n_mol_on_grain,
+      ! proceeds(1/0); then '# yiter' = the abundances the cell holds after the iteration.
+      dt0 = dt_first_step
+      t_final = 0D0
+      abund = chemsol_stor%y(1:nS)
+      qual_cell = 0
+      do jj = 1, nlocal_iter
+        if (jj .gt. 1) then
+          chemsol_stor%y(1:nS) = abund
+          chemsol_stor%y(nS + 1) = chem_params%Tgas
+          call rectify_abundances(NEQ, chemsol_stor%y)
+          chemsol_params%t0 = t_final
+          chemsol_params%dt_first_step = max(dt0, chemsol_params%t0 * 1D-3)
+          call chem_evol_solve_prepare_ongoing
+          call chem_set_solver_flags_alt(jj)
+          call chem_cal_rates
+        end if
+        call chem_evol_solve
+        t_end = chemsol_stor%touts(chemsol_params%n_record_real)
+        write(fC, '(A, I8, I8)') '# iter ', 11, jj
+        write(fC, '(ES25.17E3)') dble(jj)
+        write(fC, '(ES25.17E3)') chemsol_params%t0
+        write(fC, '(ES25.17E3)') chemsol_params%dt_first_step
+        write(fC, '(ES25.17E3)') dble(chemsol_params%n_record)
+        write(fC, '(ES25.17E3)') t_end
+        if ((jj .gt. 1) .and. (t_end .le. t_final)) then
+          ! 'Local iteration does not proceed': nothing is taken over
+          write(fC, '(ES25.17E3)') dble(qual_cell)
+          write(fC, '(ES25.17E3)') dble(chemsol_params%NERR)
+          write(fC, '(ES25.17E3)') 0D0
+          write(fC, '(ES25.17E3)') t_final
+          write(fC, '(ES25.17E3)') chem_params%n_mol_on_grain
+          write(fC, '(ES25.17E3)') 0D0
+          exit
+        end if
+        do isav = chemsol_params%n_record_real, 1, -1
+          if ((.not. isnan(chemsol_stor%record(nS + 1, isav))) .and. &
+              (.not. isnan(chemsol_stor%record(chem_idx_some_spe%i_H2, isav)))) exit
+        end do
+        qual_cell = chemsol_params%quality
+        if (isav .gt. 1) then
+          abund = chemsol_stor%record(1:nS, isav)
+          t_final = chemsol_stor%touts(isav)
+          tmp = get_ice_coverage(nS, abund)
+        end if
+        write(fC, '(ES25.17E3)') dble(qual_cell)
+        write(fC, '(ES25.17E3)') dble(chemsol_params%NERR)
+        write(fC, '(ES25.17E3)') dble(isav)
+        write(fC, '(ES25.17E3)') t_final
+        write(fC, '(ES25.17E3)') chem_params%n_mol_on_grain
+        write(fC, '(ES25.17E3)') 1D0
+        write(fC, '(A, I8, I8)') '# yiter ', nS, jj
+        do i = 1, nS
+          write(fC, '(ES25.17E3)') abund(i)
+        end do
+        if (isav .le. 1) exit
+        if ((qual_cell .eq. 0) .or. (t_final .ge. 0.5D0 * chemsol_params%t_max)) exit
+      end do
+      write(fC, '(A, I8)') '# rh2form ', 1
+      write(fC, '(ES25.17E3)') chem_params%R_H2_form_rate_coeff
+    else if (solve .ne. 0) then
       call system_clock(c0, crate)
       call chem_evol_solve
       call system_clock(c1)
@@ -197,6 +279,11 @@ program ref_driver
       write(fC, '(ES25.17E3)') dble(chemsol_params%NERR)
       write(fC, '(ES25.17E3)') dble(c1 - c0) / dble(crate)
       ! IWORK(11,12,13,21): NST NFE NJE NLU of the LAST solver segment (zeroed by every ISTATE=1)
+      write(fC, '(A, I8)') '# workspace ', 4
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(17)) ! LENRW: RWORK length DLSODES actually needs
+      write(fC, '(ES25.17E3)') dble(chemsol_params%LRW)     ! length the reference allocates (20 + 4 NNZ + 28 NEQ)
+      write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(22)) ! LYH
+      write(fC, '(ES25.17E3)') dble(chemsol_params%NNZ)
       write(fC, '(A, I8)') '# stats ', 9
       write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(11))
       write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(12))
@@ -207,6 +294,10 @@ program ref_driver
       write(fC, '(ES25.17E3)') dble(chemsol_stor%IWORK(26))
       write(fC, '(ES25.17E3)') dble(chemsol_params%n_record)
       write(fC, '(ES25.17E3)') dble(chemsol_params%n_record_real)
+      write(fC, '(A, I8)') '# sideeffects ', 2
+      tmp = get_ice_coverage(nS, chemsol_stor%y(1:nS))
+      write(fC, '(ES25.17E3)') chem_params%R_H2_form_rate_coeff
+      write(fC, '(ES25.17E3)') chem_params%n_mol_on_grain
       write(fC, '(A, I8)') '# touts ', chemsol_params%n_record
       do i = 1, chemsol_params%n_record
         write(fC, '(ES25.17E3)') chemsol_stor%touts(i)

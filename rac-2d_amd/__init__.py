@@ -31,7 +31,7 @@ O_R_H2_FORM, O_N_MOL_ON_GRAIN, O_T_END = range(NOUT)
 # every extern "C" symbol include/racgpu.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "racgpu_last_error", "racgpu_device_count", "racgpu_network_load", "racgpu_network_destroy",
-    "racgpu_network_dims", "racgpu_species_name", "racgpu_species_index", "racgpu_reactions",
+    "racgpu_network_dims", "racgpu_network_set_reference_lenrw", "racgpu_network_reference_lenrw", "racgpu_species_name", "racgpu_species_index", "racgpu_reactions",
     "racgpu_species_attrs", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
@@ -82,6 +82,8 @@ def lib():
     L.racgpu_network_destroy.argtypes = [vp]
     L.racgpu_network_dims.argtypes = [vp, ip, ip, ip, ip, ip]
     L.racgpu_species_name.argtypes = [vp, C.c_int32, C.c_char_p, C.c_int32]
+    L.racgpu_network_set_reference_lenrw.argtypes = [vp, C.c_int32]
+    L.racgpu_network_reference_lenrw.argtypes = [vp]
     L.racgpu_species_index.argtypes = [vp, C.c_char_p]
     L.racgpu_reactions.argtypes = [vp, ip, ip, ip, ip, ip, ip]
     L.racgpu_species_attrs.argtypes = [vp, dp, dp, dp, ip, ip]
@@ -169,6 +171,13 @@ class Network:
             self.close()
         except Exception:
             pass
+
+    def set_reference_lenrw(self, lenrw):
+        """IWORK(17) of the reference's DLSODES for this network (0: unknown, the saved P survives ISTATE = 3); see racgpu.h."""
+        _check(lib().racgpu_network_set_reference_lenrw(self._h, int(lenrw)))
+
+    def reference_lenrw(self):
+        return lib().racgpu_network_reference_lenrw(self._h)
 
     # ---- host-only queries -------------------------------------------------------------------------
     def species_index(self, name):

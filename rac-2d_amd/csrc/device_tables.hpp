@@ -46,6 +46,10 @@ struct DevNet {
   const uint16_t *perm;      // perm[new] = old
   const uint16_t *Lrow, *Urow, *Prow; // storage layout: see network.hpp, struct Symbolic
   const uint8_t *Pdiag;       // [nnzJ] in storage order: 1 on the diagonal
+  // ISTATE = 3 in the reference zeroes the entries of the saved P whose position in ITS storage is >= ref_nnz1 - Z,
+  // Z = ref_zbase + NEQ * min(nq + 1, 7) (network.hpp, HostNetwork::ref_kref); ref_clobber = 0: unknown layout, nothing is zeroed
+  const uint16_t *Pkref;      // [nnzJ] in storage order: position in the reference's storage
+  int ref_nnz1, ref_zbase, ref_clobber;
   // triangular-solve schedules: one packed word per stored entry of the streamed part, row | col<<10 |
   // (next chunk continues this level)<<20; chunks of 64 entries hold one dependency level each; null: row == col
   const uint32_t *Lrc, *Urc;

@@ -276,6 +276,11 @@ struct racgpu_network {
     return (const T *)d;
   }
   void upload();
+  void set_ref_layout() { // Z of an ISTATE = 3 call: LREQ - 4 NNZ0 - 28 NEQ + NNZ1 + NEQ * NCOLM with LREQ = LENRW - 20 - 9 NEQ
+    const int neq = net.nS + 1;
+    dn.ref_nnz1 = net.ref_nnz1; dn.ref_clobber = net.ref_lenrw > 0 ? 1 : 0;
+    dn.ref_zbase = (net.ref_lenrw - 20 - 9 * neq) - 4 * net.ref_nnz0 - 28 * neq + net.ref_nnz1;
+  }
   void ensure_workspace(long slots, long rate_cells);
   void free_ws() { for (void *p : ws_allocs) (void)hipFree(p); ws_allocs.clear(); ws_slots = 0; ws_rate_cells = 0; }
   ~racgpu_network() {
@@ -412,6 +417,10 @@ void racgpu_network::upload() {
         for (int q = h.Jcolptr[j]; q < h.Jcolptr[j + 1]; ++q) if (h.Jrow[q] == j) pd[S.Ppos[q]] = 1;
       pd.resize(pd.size() + 64, 0); // read in whole blocks of 64
       dn.Pdiag = up(pd);
+      std::vector<uint16_t> kr(S.Psrc.size() + 64, 0);
+      if (h.ref_nnz1 > 65535) throw std::runtime_error("reference pattern too large for 16-bit storage positions");
+      for (size_t q = 0; q < S.Psrc.size(); ++q) kr[q] = (uint16_t)h.ref_kref[S.Psrc[q]];
+      dn.Pkref = up(kr);
     }
     auto pack = [](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, size_t nstream, int &nchunk) {
       // the streamed part only (the dense trailing block is solved in registers); the storage is level-aligned, so
@@ -504,6 +513,7 @@ void racgpu_network::upload() {
     for (int i = 0; i < nS; ++i) chg[i] = (int8_t)h.elements[i][0];
     dn.s_charge = up(chg);
   }
+  set_ref_layout();
   dn.i_H2 = h.idx10[0] - 1;
   dn.r_h2form = -1; // chem_cal_rates stores the coefficient of every itype-0 and every gH-first itype-63 reaction in turn: the last one stays
   for (int r = 0; r < nR; ++r)
@@ -624,6 +634,18 @@ int racgpu_network_dims(const racgpu_network *h, int32_t *nS, int32_t *nR, int32
   if (nzu) *nzu = h->net.sym.nzu_entries;
   return 0;
 }
+
+int racgpu_network_set_reference_lenrw(racgpu_network *h, int32_t lenrw) {
+  if (!h) return fail("null network");
+  if (lenrw < 0) return fail("lenrw must be >= 0");
+  return guarded([&] {
+    h->net.ref_lenrw = lenrw;
+    h->set_ref_layout();
+    if (h->uploaded) HIP_OK(hipMemcpy(h->dn_dev, &h->dn, sizeof(DevNet), hipMemcpyHostToDevice));
+  });
+}
+
+int racgpu_network_reference_lenrw(const racgpu_network *h) { return h ? h->net.ref_lenrw : -1; }
 
 int racgpu_species_name(const racgpu_network *h, int32_t i, char *buf, int32_t buflen) {
   if (!h || i < 1 || i > h->net.nS || buflen < 1) return fail("bad species index");

@@ -392,10 +392,20 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
   if (istate != 1 && s.init == 0) { istate = -3; return; }
   if (istate == 1) { s.init = 0; if (tout == t) return; }
   if (istate == 3) {
-    // DIPREP/DPREP rerun on ISTATE=3 with an unchanged layout: the saved P survives (the words DPREP zeroes,
-    // reference src/opkda1.f:1487-1494, are a temporary copy at the far end of the work array), so DPRJS may
-    // rescale it.  Only the "parameters changed" flag is raised.
+    // DIPREP/DPREP rerun on ISTATE=3 with an unchanged layout: the words DPREP zeroes (reference src/opkda1.f:1487-1494)
+    // lie at the far end of a temporary work area, not at the saved P, so DPRJS may rescale what survives of it (below);
+    // the "parameters changed" flag is raised.
     s.jstart = -1;
+    // What the reference's rerun does do to the saved P: with the RWORK length the reference allocates, the zeroed words
+    // overlap P's tail, NCOLM = min(nq + 1, MAXORD + 2) columns of YH deciding by how much (device_tables.hpp, Pkref).
+    if (N.ref_clobber) {
+      const int z = N.ref_zbase + (n + 1) * min(s.nq + 1, kMaxord + 2), thresh = N.ref_nnz1 - z;
+      if (z > 0) {
+        const rsrc_t bP = mkbuf(c.Pv), bK = mkbuf(N.Pkref);
+        for (int e0 = 0; e0 < N.nnzJ; e0 += 64)
+          if (e0 + lane < N.nnzJ && (int)bload_u16(bK, lane * 2, e0 * 2) >= thresh) bstore_f64(bP, l8, e0 * 8, 0.0);
+      }
+    }
   }
   if (istate == 1) { // Block C
     s.h0 = 0.0;

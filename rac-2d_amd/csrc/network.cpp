@@ -228,6 +228,7 @@ void parse_network(const std::string &path, HostNetwork &net) {
   }
   build_jacobian_tables(net);
   build_symbolic(net);
+  build_reference_layout(net);
 }
 
 void load_initial_abundances(const HostNetwork &net, const std::string &path, double *y0) {
@@ -476,6 +477,45 @@ void build_symbolic(HostNetwork &net) {
   }
   S.Ppos.assign(S.Psrc.size(), 0);
   for (size_t q = 0; q < S.Psrc.size(); ++q) S.Ppos[S.Psrc[q]] = (int)q;
+}
+
+// The reference's pattern and the storage order of its P (see HostNetwork::ref_kref).
+void build_reference_layout(HostNetwork &net) {
+  const int nS = net.nS, neq = nS + 1;
+  std::vector<std::vector<int>> col(neq); // rows per column
+  for (const Reaction &x : net.R)
+    for (int j = 0; j < x.n_reac && j < 3; ++j) {
+      const int cj = x.reac[j] - 1;
+      for (int k = 0; k < x.n_reac && k < 3; ++k) col[cj].push_back(x.reac[k] - 1);
+      for (int k = 0; k < x.n_prod && k < 4; ++k) col[cj].push_back(x.prod[k] - 1);
+    }
+  for (int k = 0; k < 10; ++k) if (net.idx10[k] > 0) col[net.idx10[k] - 1].push_back(nS); // the T row at the special species
+  col[nS].clear();
+  for (int i = 0; i < neq; ++i) col[nS].push_back(i);                                        // the full T column
+  net.ref_nnz0 = 0;
+  std::vector<int> start(neq + 1, 0);
+  for (int j = 0; j < neq; ++j) {
+    auto &v = col[j];
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    net.ref_nnz0 += (int)v.size();
+    if (!std::binary_search(v.begin(), v.end(), j)) v.push_back(j); // DPREP appends a missing diagonal entry
+    start[j + 1] = start[j] + (int)v.size();
+  }
+  net.ref_nnz1 = start[neq];
+  net.ref_kref.assign(net.Jrow.size(), 0);
+  for (int j = 0; j < nS; ++j)
+    for (int q = net.Jcolptr[j]; q < net.Jcolptr[j + 1]; ++q) {
+      const auto it = std::find(col[j].begin(), col[j].end(), net.Jrow[q]);
+      if (it == col[j].end()) throw std::runtime_error("pattern entry outside the reference's pattern");
+      net.ref_kref[q] = start[j] + (int)(it - col[j].begin());
+    }
+  // IWORK(17) (LENRW) as the reference's DLSODES reports it for the networks shipped in data/ (measured with
+  // oracle/_ref/ref_driver, section '# workspace'); it depends on YSMP's compressed index storage and cannot be derived
+  // without it.  Other networks: racgpu_network_set_reference_lenrw, or 0 = the saved P is taken to survive ISTATE = 3.
+  static const struct { int nS, nR, lenrw; } known[] = {{464, 4767, 59430}, {467, 4801, 60324}, {484, 5830, 65578}, {524, 6425, 82134}};
+  net.ref_lenrw = 0;
+  for (const auto &k : known) if (k.nS == nS && k.nR == net.nR) net.ref_lenrw = k.lenrw;
 }
 
 } // namespace racgpu

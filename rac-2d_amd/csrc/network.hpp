@@ -76,6 +76,14 @@ struct HostNetwork {
   std::vector<int> term_ptr;       // per Jacobian entry
   std::vector<JacTerm> terms;      // in reference accumulation order (reaction order, reactant slots then product slots)
   Symbolic sym;
+  // Where every entry of OUR pattern sits in the reference's own storage of P (DLSODES' WM segment): position in the
+  // column-major IAN/JAN arrays DPREP builds from chem_make_sparse_structure's mask (reference src/chemistry.f90:1858-1885,
+  // 1962-1972; src/opkda1.f:1386-1410: a missing diagonal entry is appended to its column).  Needed for one thing only:
+  // on an ISTATE = 3 call DPREP zeroes NNZ words at the far end of a temporary work area (src/opkda1.f:1487-1494) which,
+  // with the RWORK length the reference allocates (20 + 4 NNZ + 28 NEQ), overlaps the tail of the saved P.
+  int ref_nnz0 = 0, ref_nnz1 = 0;   // entries of the reference's mask / of IAN-JAN with the diagonal added
+  std::vector<int> ref_kref;        // per entry of Jrow (CSC order): 0-based position in that storage
+  int ref_lenrw = 0;                // IWORK(17) of the reference's DLSODES for this network (0 = unknown: P is taken to survive)
 
   int species_index(const std::string &name) const; // 1-based, 0 if absent
   Kind kind(int r) const;
@@ -87,6 +95,7 @@ void parse_network(const std::string &path, HostNetwork &net);
 void load_initial_abundances(const HostNetwork &net, const std::string &path, double *y0);
 void build_jacobian_tables(HostNetwork &net);
 void build_symbolic(HostNetwork &net);
+void build_reference_layout(HostNetwork &net);
 double fortran_real_field(const char *s, int w);
 
 } // namespace racgpu

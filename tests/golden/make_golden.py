@@ -59,17 +59,28 @@ def read_cell(fn):
     return {k: np.array(v) for k, v in d.items()}
 
 
-def run_ref(network, initial, cells, rtol, t_max, steps_reset, dump_jac, solve=1):
+def run_ref(network, initial, cells, rtol, t_max, steps_reset, dump_jac, solve=1, atol=1e-30, mxstep=6000, nlocal_iter=1, tol_j=1,
+            y_override=None, special_gH_mobi=False):
+    """y_override: list of (cell (1-based), species (1-based), value) applied to the initial condition."""
     with tempfile.TemporaryDirectory() as td:
         np.savetxt(os.path.join(td, "cells.txt"), cells, fmt="%.17e")
+        ov = ""
+        if y_override:
+            with open(os.path.join(td, "override.txt"), "w") as f:
+                for c, sp, v in y_override:
+                    f.write("%d %d %.17e\n" % (c, sp, v))
+            ov = " y_override='%s'\n" % os.path.join(td, "override.txt")
         with open(os.path.join(td, "run.nml"), "w") as f:
             f.write("&ref_run\n chem_dir='%s'\n network='%s'\n initial='%s'\n out_dir='%s'\n cell_file='%s'\n"
-                    " ncell=%d\n rtol=%.17e\n atol=1D-30\n dt_first_step=1D-8\n ratio_tstep=1.1D0\n t_max=%.17e\n"
-                    " mxstep=6000\n steps_reset=%d\n dump_jac=%d\n solve=%d\n/\n"
-                    % (INP, network, initial, td, os.path.join(td, "cells.txt"), len(cells), rtol, t_max,
-                       steps_reset, dump_jac, solve))
+                    " ncell=%d\n rtol=%.17e\n atol=%.17e\n dt_first_step=1D-8\n ratio_tstep=1.1D0\n t_max=%.17e\n"
+                    " mxstep=%d\n steps_reset=%d\n dump_jac=%d\n solve=%d\n nlocal_iter=%d\n tol_j=%d\n special_gH_mobi=%s\n%s/\n"
+                    % (INP, network, initial, td, os.path.join(td, "cells.txt"), len(cells), rtol, atol, t_max,
+                       mxstep, steps_reset, dump_jac, solve, nlocal_iter, tol_j, ".true." if special_gH_mobi else ".false.", ov))
         subprocess.run([DRIVER, os.path.join(td, "run.nml")], stdout=subprocess.DEVNULL, check=True)
         out = [read_cell(os.path.join(td, "cell_%04d.txt" % (i + 1))) for i in range(len(cells))]
+        log = open(os.path.join(td, "ref_log.txt")).read()
+        for o in out:
+            o["_log"] = log
         meta = dict(
             species=[l.rstrip("\n") for l in open(os.path.join(td, "species.txt"))],
             network=np.loadtxt(os.path.join(td, "network.txt"), skiprows=1, dtype=np.int32),
@@ -127,5 +138,79 @@ def main():
         print("wrote", fn, os.path.getsize(fn) // 1024, "KiB")
 
 
+def iters_of(o, nS):
+    """The '# iter' / '# yiter' sections of one cell -> (table [niter, 11], abundances [niter, nS]); columns of the table:
+    j, t0, dt_first_step, n_record, touts(n_record_real), quality, NERR, isav, t_final, n_mol_on_grain, proceeds."""
+    js = sorted(int(k.split("_")[1]) for k in o if k.startswith("iter_"))
+    tab = np.array([o["iter_%d" % j] for j in js])
+    ys = np.array([o.get("yiter_%d" % j, np.full(nS, np.nan)) for j in js])
+    return tab, ys
+
+
+def main_policy():
+    """tests/golden/policy_grain.npz: the policy paths of chem_evol_solve and of calc_this_cell's local-iteration loop on
+    cells of the configs[2] grid (network rate06 with grains): per-cell t_max below t_max0, tolerance policies j = 2, 3, 5,
+    use_special_gH_mobi, ISTATE = -1 returns with retries from t_final (nlocal_iter = 4), the ISTATE = -3 / quality 256 exit
+    (ATOL = 0) and the quality 512 sanity exit (abundance of H forced to 2.5)."""
+    andrews_grid = importlib.import_module("rac-2d_amd.cells").andrews_grid
+    grid = andrews_grid()
+    network, initial = "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "ini_abund_waterice_loMetal.dat"
+    out = dict(network_file=network, initial_file=initial)
+    _, meta = run_ref(network, initial, grid[:1], 1e-4, 1e6, 50, 0, solve=0)
+    species = meta["species"]; nS = len(species)
+    out["species"] = np.array(species); out["y0"] = meta["y0"]
+    iH = species.index("H") + 1
+
+    # (1) cells of the grid, one plain pass at the template settings and at RTOL 1e-8: per-cell t_max (orbit rule), side effects
+    idx = np.array([20, 452, 3817, 8696, 11412, 14998, 15952, 19233])
+    cfg, _ = run_ref(network, initial, grid[idx], 1e-4, 1e6, 50, 0)
+    tight, _ = run_ref(network, initial, grid[idx], 1e-8, 1e6, 50, 0)
+    out.update(grid_idx=idx, grid_cells=grid[idx],
+               grid_yend=np.array([c["yend"] for c in cfg]), grid_scalars=np.array([c["scalars"][:3] for c in cfg]),
+               grid_stats=np.array([c["stats"] for c in cfg]), grid_side=np.array([c["sideeffects"] for c in cfg]),
+               grid_yend_tight=np.array([c["yend"] for c in tight]), grid_scalars_tight=np.array([c["scalars"][:3] for c in tight]),
+               grid_log=np.array(cfg[0]["_log"]))
+
+    # (2) tolerance policies j = 2, 3, 5 and use_special_gH_mobi, RTOL 1e-8 so that the end states are comparable
+    pc = grid[[8696, 15952]]
+    for j in (2, 3, 5):
+        r, _ = run_ref(network, initial, pc, 1e-8, 1e6, 50, 0, tol_j=j)
+        out["tolj%d_yend" % j] = np.array([c["yend"] for c in r]); out["tolj%d_scalars" % j] = np.array([c["scalars"][:3] for c in r])
+        out["tolj%d_rtol" % j] = np.array([c["rtol"] for c in r]); out["tolj%d_atol" % j] = np.array([c["atol"] for c in r])
+    r, _ = run_ref(network, initial, pc, 1e-8, 1e6, 50, 0, special_gH_mobi=True)
+    out.update(policy_cells=pc, gHmobi_yend=np.array([c["yend"] for c in r]), gHmobi_rates=np.array([c["rates"] for c in r]),
+               gHmobi_scalars=np.array([c["scalars"][:3] for c in r]))
+
+    # (3) ISTATE = -1 ("excess work") on almost every interval: mxstep = 6, then the caller's retries from t_final
+    r, _ = run_ref(network, initial, pc, 1e-4, 1e6, 50, 0, mxstep=6, nlocal_iter=4)
+    tabs = [iters_of(c, nS) for c in r]
+    out["retry_mxstep"] = 6
+    for k, (tab, ys) in enumerate(tabs):
+        out["retry%d_iters" % k] = tab; out["retry%d_y" % k] = ys
+    r1, _ = run_ref(network, initial, pc, 1e-4, 1e6, 50, 0, mxstep=6)
+    out["mxstep6_scalars"] = np.array([c["scalars"][:3] for c in r1]); out["mxstep6_stats"] = np.array([c["stats"] for c in r1])
+    out["mxstep6_yend"] = np.array([c["yend"] for c in r1])
+
+    # (4) ISTATE = -3 at the first call (a zero error weight: ATOL = 0 and species absent initially): quality 256 + 2
+    r, _ = run_ref(network, initial, pc[:1], 1e-4, 1e6, 50, 0, atol=0.0, nlocal_iter=4)
+    tab, ys = iters_of(r[0], nS)
+    out["atol0_iters"] = tab; out["atol0_y"] = ys
+
+    # (5) sanity exit: |X(H)| > 2 after the first interval: quality 512 + 2
+    r, _ = run_ref(network, initial, pc[:1], 1e-4, 1e6, 50, 0, y_override=[(1, iH, 2.5)], nlocal_iter=4)
+    tab, ys = iters_of(r[0], nS)
+    out["bigH_iters"] = tab; out["bigH_y"] = ys; out["bigH_species"] = iH
+
+    fn = os.path.join(HERE, "policy_grain.npz")
+    np.savez_compressed(fn, **out)
+    print("wrote", fn, os.path.getsize(fn) // 1024, "KiB")
+    for k in ("grid_scalars", "mxstep6_scalars", "atol0_iters", "bigH_iters", "retry0_iters", "retry1_iters"):
+        print(k, "\n", out[k])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "policy":
+        main_policy()
+    else:
+        main()
+        main_policy()

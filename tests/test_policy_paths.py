@@ -1,0 +1,233 @@
+"""The policy paths of chem_evol_solve and of calc_this_cell's local-iteration loop, against tuples captured from the
+UNMODIFIED reference (tests/golden/policy_grain.npz, generator tests/golden/make_golden.py policy; cells of the configs[2]
+grid, network rate06 with grains):
+
+  * per-cell t_max below t_max0 (orbit rule), side effects R_H2_form_rate_coeff and n_mol_on_grain
+  * tolerance policies j = 2, 3, 5 of chem_set_solver_flags_alt and use_special_gH_mobi
+  * ISTATE = -1 on almost every interval (mxstep = 6), retries from t_final with policies 2, 3, 4
+  * ISTATE = -3 at the first call (ATOL = 0): quality 256 + 2, "Local iteration does not proceed"
+  * the sanity exit (|X(H)| > 2): quality 512 + 2, restarts that gain one interval each
+
+CPU part: the oracle (C restatement) and the product's host-side functions against the tuples.  GPU part (-m gpu): the
+engine through the C ABI against the same tuples.
+
+Tolerances.  Exits that happen at the first interval are deterministic: everything is compared exactly (times to 1e-14).
+Runs that take error returns follow the reference only statistically: after every ISTATE < 0 return the reference re-enters
+with ISTATE = 3 and a partly zeroed Newton matrix, which both the oracle and the engine model, but from
+there the step sequences drift (a different elimination order inside one column is enough), so NERR and quality must agree
+and the times reached must agree within a factor 4 (they span 12 decades over the run)."""
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN, major_relerr
+
+G = np.load(f"{GOLDEN}/policy_grain.npz")
+NET = f"{DATA}/{G['network_file']}"
+# columns of the '# iter' tuples
+J, T0, DT1, NREC, TEND, QUAL, NERR, ISAV, TFIN, NMOL, PROC = range(11)
+
+
+def _params(mod, **kw):
+    p = mod.default_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+# ------------------------------------------------------------------------------------------------------------ CPU: host side
+def test_host_tolerance_policies_bit_equal(racgpu):
+    net = racgpu.Network(NET)
+    for j in (2, 3, 5):
+        p = _params(racgpu, RTOL=1e-8)
+        for c, cell in enumerate(G["policy_cells"]):
+            rt, at = net.set_solver_flags_alt(p, j, cell[6])
+            np.testing.assert_array_equal(rt, G[f"tolj{j}_rtol"][c])
+            np.testing.assert_array_equal(at, G[f"tolj{j}_atol"][c])
+
+
+def test_host_rectify_abundances(racgpu, oracle):
+    net = racgpu.Network(NET)
+    y = net.init_abundances(G["y0"], G["policy_cells"])
+    y[:, net.species_index("HCO+") - 1] += 1e-9  # unbalance the charge
+    out = net.rectify_abundances(y)
+    at = net.species_attrs()
+    np.testing.assert_allclose((out * at["charge"]).sum(axis=1), 0.0, atol=1e-24)
+    iE = net.species_index("E-") - 1
+    mask = np.ones(net.nSpecies, bool); mask[iE] = False
+    np.testing.assert_array_equal(out[:, mask], y[:, mask])
+
+
+def test_reference_lenrw_is_known_for_the_shipped_networks(racgpu):
+    for f, lenrw in (("rate06_dipole_reformated_again_withoutgrain.dat", 59430), ("rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", 60324),
+                     ("rate06_withgrain_lowH2Bind_hiOBind_lowCObind.dat", 65578), ("rate12_withGrain_lowH2Bind_hiObind.dat", 82134)):
+        net = racgpu.Network(f"{DATA}/{f}")
+        assert net.reference_lenrw() == lenrw
+        net.set_reference_lenrw(0); assert net.reference_lenrw() == 0
+
+
+# ------------------------------------------------------------------------------------------------------------ CPU: the oracle
+def test_oracle_grid_cells_with_their_own_tmax(oracle):
+    onet = oracle.Network(NET)
+    op = oracle.default_params()
+    for k, cell in enumerate(G["grid_cells"][:4]):  # the four cells with t_max below t_max0
+        o = onet.solve_cell(op, cell, G["y0"])
+        assert o["t_final"] == G["grid_scalars"][k, 0] == cell[27]
+        assert o["quality"] == int(G["grid_scalars"][k, 1])
+        assert o["n_record_real"] == int(G["grid_stats"][k, 8])  # n_record follows the CELL's t_max (chem_evol_solve_prepare_ongoing)
+        assert major_relerr(o["y"][:onet.nS], G["grid_yend"][k][:onet.nS]) <= 1e-3
+
+
+def test_oracle_exits_at_the_first_interval(oracle):
+    onet = oracle.Network(NET)
+    cell = G["policy_cells"][0]
+    # ATOL = 0: a zero error weight, ISTATE = -3 at the first call
+    r = onet.calc_cell(_params(oracle, ATOL=0.0), cell, G["y0"], 4)
+    ref = G["atol0_iters"]
+    assert r["rc"] == len(ref) == 2
+    for it, row in zip(r["iters"], ref):
+        assert (it["t0"], it["t_end"], it["quality"], it["nerr"], it["proceeds"]) == (row[T0], row[TEND], int(row[QUAL]), int(row[NERR]), int(row[PROC]))
+    assert r["quality"] == 258 and r["t_final"] == 0.0
+    np.testing.assert_array_equal(r["y"], G["atol0_y"][0])
+    # X(H) = 2.5: quality 512 + 2 after one interval, every local iteration gains one interval
+    yi = onet.initial_state(G["y0"], cell)[:onet.nS]; yi[int(G["bigH_species"]) - 1] = 2.5
+    r = onet.calc_cell(oracle.default_params(), cell, G["y0"], 4, y_init=yi)
+    ref = G["bigH_iters"]
+    assert r["rc"] == len(ref) == 4
+    for it, row in zip(r["iters"], ref):
+        assert it["quality"] == int(row[QUAL]) == 514 and it["isav"] == int(row[ISAV]) == 2
+        np.testing.assert_allclose([it["t0"], it["t_end"], it["t_final"], it["dt_first"]], [row[T0], row[TEND], row[TFIN], row[DT1]], rtol=1e-14)
+        np.testing.assert_allclose(it["n_mol_on_grain"], row[NMOL], rtol=1e-12)
+    np.testing.assert_allclose(r["y"], G["bigH_y"][-1], rtol=1e-4, atol=1e-30)  # four RTOL = 1e-4 integrations of one interval each
+
+
+def _check_retry(iters, ref, k):
+    assert len(iters) == len(ref), (k, len(iters), len(ref))
+    for it, row in zip(iters, ref):
+        assert it["quality"] == int(row[QUAL]), (k, it, row)
+        assert it["proceeds"] == int(row[PROC])
+        assert abs(it["nerr"] - row[NERR]) <= max(3, 0.1 * row[NERR]), (k, it["nerr"], row[NERR])
+        assert 0.25 <= it["t_end"] / row[TEND] <= 4.0, (k, it["t_end"], row[TEND])
+
+
+def test_oracle_retry_loop_after_istate_minus_one(oracle):
+    onet = oracle.Network(NET)
+    op = _params(oracle, mxstep_per_interval=int(G["retry_mxstep"]))
+    for k, cell in enumerate(G["policy_cells"]):
+        o1 = onet.solve_cell(op, cell, G["y0"])
+        assert o1["quality"] == int(G["mxstep6_scalars"][k, 1]) and o1["nerr"] == int(G["mxstep6_scalars"][k, 2])
+        assert 0.25 <= o1["t_final"] / G["mxstep6_scalars"][k, 0] <= 4.0
+        r = onet.calc_cell(op, cell, G["y0"], 4)
+        ref = G[f"retry{k}_iters"]
+        # the continue rule is deterministic given t_final: t0 = t_final, first step max(dt0, 1e-3 t0)
+        for a, b in zip(r["iters"][:-1], r["iters"][1:]):
+            assert b["t0"] == a["t_final"] and b["dt_first"] == max(op.dt_first_step, 1e-3 * b["t0"])
+        for row_a, row_b in zip(ref[:-1], ref[1:]):
+            assert row_b[T0] == row_a[TFIN] and row_b[DT1] == max(1e-8, 1e-3 * row_b[T0])
+        _check_retry(r["iters"][:2], ref[:2], k)  # later iterations start from drifted states
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_grid_cells_side_effects_and_tmax(racgpu):
+    net = racgpu.Network(NET)
+    cells = G["grid_cells"]
+    out = net.evol_solve_batch(racgpu.default_params(), cells, net.init_abundances(G["y0"], cells))
+    for k in range(len(cells)):
+        assert out["t_final"][k] == G["grid_scalars"][k, 0]
+        assert out["quality"][k] == int(G["grid_scalars"][k, 1])
+        assert out["stats"][k, racgpu.S_NREC_REAL] == int(G["grid_stats"][k, 8])
+        assert out["stats"][k, racgpu.S_ISAV] == out["stats"][k, racgpu.S_NREC_REAL]
+        np.testing.assert_allclose(out["cell_out"][k, racgpu.O_R_H2_FORM], G["grid_side"][k, 0], rtol=1e-12)
+        # n_mol_on_grain is a sum over the surface species of the end state: as close to the reference as the end state is
+        np.testing.assert_allclose(out["cell_out"][k, racgpu.O_N_MOL_ON_GRAIN], G["grid_side"][k, 1], rtol=1e-3)
+        assert out["cell_out"][k, racgpu.O_T_END] == out["t_final"][k]
+        assert major_relerr(out["y"][k], G["grid_yend"][k][:net.nSpecies]) <= 3e-3
+    p8 = _params(racgpu, RTOL=1e-8)
+    out = net.evol_solve_batch(p8, cells, net.init_abundances(G["y0"], cells))
+    for k in range(len(cells)):
+        err = major_relerr(out["y"][k], G["grid_yend_tight"][k][:net.nSpecies])
+        print(f"grid cell {int(G['grid_idx'][k])}: GPU(1e-8) vs reference(1e-8) {err:.2e}")
+        assert out["t_final"][k] == G["grid_scalars_tight"][k, 0] and out["quality"][k] == 0
+        assert err <= 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_tolerance_policies_and_special_gh_mobility(racgpu):
+    net = racgpu.Network(NET)
+    cells = G["policy_cells"]
+    y = net.init_abundances(G["y0"], cells)
+    p = _params(racgpu, RTOL=1e-8)
+    for j in (2, 3, 5):
+        a = net.evol_solve_batch(_params(racgpu, RTOL=1e-8, tol_policy_j=j), cells, y)      # policy for the whole call
+        b = net.evol_solve_batch(p, cells, y, tol_j=[j, j])                                  # policy per cell
+        np.testing.assert_array_equal(a["y"], b["y"])
+        for k in range(len(cells)):
+            err = major_relerr(a["y"][k], G[f"tolj{j}_yend"][k][:net.nSpecies])
+            print(f"policy j={j} cell {k}: GPU vs reference {err:.2e}")
+            assert a["t_final"][k] == G[f"tolj{j}_scalars"][k, 0] and a["quality"][k] == int(G[f"tolj{j}_scalars"][k, 1])
+            assert err <= 1e-4
+    pm = _params(racgpu, RTOL=1e-8, use_special_gH_mobi=1)
+    k_gpu = net.cal_rates(pm, cells)
+    ref = G["gHmobi_rates"]
+    assert ((k_gpu == 0) == (ref == 0)).all()
+    nz = ref != 0
+    assert np.max(np.abs(k_gpu[nz] - ref[nz]) / np.abs(ref[nz])) <= 1e-12
+    assert (k_gpu != net.cal_rates(p, cells)).any()  # the switch does change rates
+    out = net.evol_solve_batch(pm, cells, y)
+    for k in range(len(cells)):
+        assert major_relerr(out["y"][k], G["gHmobi_yend"][k][:net.nSpecies]) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_exits_at_the_first_interval(racgpu):
+    net = racgpu.Network(NET)
+    cell = G["policy_cells"][:1]
+    y = net.init_abundances(G["y0"], cell)
+    r = net.calc_cells(_params(racgpu, ATOL=0.0), cell, y, nlocal_iter=4)
+    assert r["quality"][0] == 258 and r["t_final"][0] == 0.0
+    assert r["stats"][0, racgpu.S_NERR] == 1
+    assert r["stats"][0, racgpu.S_NITER] == 1  # iteration 2 ran and did not proceed: nothing taken over
+    np.testing.assert_array_equal(r["y"][0], G["atol0_y"][0])
+    yb = y.copy(); yb[0, int(G["bigH_species"]) - 1] = 2.5
+    r = net.calc_cells(racgpu.default_params(), cell, yb, nlocal_iter=4)
+    ref = G["bigH_iters"]
+    assert r["quality"][0] == 514 and r["stats"][0, racgpu.S_NITER] == 4 and r["stats"][0, racgpu.S_ISAV] == 2
+    np.testing.assert_allclose(r["t_final"][0], ref[-1][TFIN], rtol=1e-14)
+    np.testing.assert_allclose(r["cell_out"][0, racgpu.O_N_MOL_ON_GRAIN], ref[-1][NMOL], rtol=1e-9)
+    np.testing.assert_allclose(r["y"][0], G["bigH_y"][-1], rtol=1e-4, atol=1e-30)
+    # one iteration at a time through the low-level call reproduces the loop: t0, rectify, tolerance policy j
+    yy, t0 = yb.copy(), 0.0
+    for j in range(1, 5):
+        o = net.evol_solve_batch(racgpu.default_params(), cell, yy, t0=[t0], tol_j=[j], rectify=(j > 1))
+        np.testing.assert_allclose([o["t_final"][0], o["cell_out"][0, racgpu.O_T_END]], [ref[j - 1][TFIN], ref[j - 1][TEND]], rtol=1e-14)
+        assert o["quality"][0] == 514 and o["stats"][0, racgpu.S_NREC] == int(ref[j - 1][NREC])
+        yy, t0 = o["y"], float(o["t_final"][0])
+    np.testing.assert_array_equal(yy, r["y"])
+
+
+@pytest.mark.gpu
+def test_gpu_retry_loop_after_istate_minus_one(racgpu, oracle):
+    net = racgpu.Network(NET)
+    cells = G["policy_cells"]
+    y = net.init_abundances(G["y0"], cells)
+    p = _params(racgpu, mxstep_per_interval=int(G["retry_mxstep"]))
+    o1 = net.evol_solve_batch(p, cells, y)
+    for k in range(len(cells)):
+        assert o1["quality"][k] == int(G["mxstep6_scalars"][k, 1])
+        assert o1["stats"][k, racgpu.S_NERR] == int(G["mxstep6_scalars"][k, 2])
+        assert 0.25 <= o1["t_final"][k] / G["mxstep6_scalars"][k, 0] <= 4.0
+    r = net.calc_cells(p, cells, y, nlocal_iter=4)
+    onet = oracle.Network(NET)
+    op = _params(oracle, mxstep_per_interval=int(G["retry_mxstep"]))
+    for k in range(len(cells)):
+        ref = G[f"retry{k}_iters"]
+        print(f"cell {k}: GPU iterations {r['stats'][k, racgpu.S_NITER]} t_final {r['t_final'][k]:.4g} quality {r['quality'][k]}; reference {len(ref)} "
+              f"{ref[-1][TFIN]:.4g} {int(ref[-1][QUAL])}")
+        assert r["stats"][k, racgpu.S_NITER] >= 2           # the retry did run
+        assert r["t_final"][k] > o1["t_final"][k]           # and got further
+        # batch of two = each cell alone, and the loop = the oracle's loop on the same arithmetic path up to rounding
+        solo = net.calc_cells(p, cells[k:k + 1], y[k:k + 1], nlocal_iter=4)
+        np.testing.assert_array_equal(solo["y"][0], r["y"][k])
+        assert solo["t_final"][0] == r["t_final"][k] and solo["quality"][0] == r["quality"][k]
+        o = onet.calc_cell(op, cells[k], G["y0"], 4)
+        assert r["quality"][k] in (o["quality"], int(ref[-1][QUAL]))
