@@ -215,7 +215,7 @@ __global__ void k_gather_pass(int nsel, const int *__restrict__ sel, int nS, con
 // merge what local iteration j > 1 produced for the selected cells, in the order calc_this_cell applies it:
 //   touts(n_record_real) <= t_final of the previous iteration -> "does not proceed": nothing is taken over;
 //   quality is taken over; isav <= 1 -> "No useful data": abundances and t_final stay; else both are taken over.
-// The work counters add up over the iterations; NERR, n_record_real, isav, n_record are the last iteration's.
+// The work counters add up over the iterations; NERR, n_record_real, isav, n_record are those of the last iteration that proceeded.
 __global__ void k_merge_pass(int nsel, const int *__restrict__ sel, int nS, int j, const double *__restrict__ y_c, const double *__restrict__ t_final_c,
                              const int *__restrict__ quality_c, const long long *__restrict__ stats_c, const double *__restrict__ out_c,
                              double *__restrict__ y, double *__restrict__ t_final, int *__restrict__ quality, long long *__restrict__ stats,
@@ -230,11 +230,11 @@ __global__ void k_merge_pass(int nsel, const int *__restrict__ sel, int nS, int 
     static const int kAdd[] = {RACGPU_S_NST, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_QSUM, RACGPU_S_NCFAIL_ETFAIL, RACGPU_S_CYC_TOTAL,
                                RACGPU_S_CYC_RHS, RACGPU_S_CYC_JAC, RACGPU_S_CYC_LU, RACGPU_S_CYC_SOLVE, 13, 14, 15};
     for (int k : kAdd) s[k] += sc[k];
-    s[RACGPU_S_NITER] = j;
-    s[RACGPU_S_NERR] = sc[RACGPU_S_NERR]; s[RACGPU_S_NREC_REAL] = sc[RACGPU_S_NREC_REAL]; s[RACGPU_S_ISAV] = sc[RACGPU_S_ISAV];
-    s[RACGPU_S_NREC] = sc[RACGPU_S_NREC];
-    if (cell_out) cell_out[(size_t)cell * RACGPU_NOUT + RACGPU_O_T_END] = out_c[(size_t)f * RACGPU_NOUT + RACGPU_O_T_END];
-    if (proceeds) {
+    if (proceeds) { // (an iteration that does not proceed leaves NITER behind: the host loop stops the cell on that)
+      s[RACGPU_S_NITER] = j;
+      s[RACGPU_S_NERR] = sc[RACGPU_S_NERR]; s[RACGPU_S_NREC_REAL] = sc[RACGPU_S_NREC_REAL]; s[RACGPU_S_ISAV] = sc[RACGPU_S_ISAV];
+      s[RACGPU_S_NREC] = sc[RACGPU_S_NREC];
+      if (cell_out) cell_out[(size_t)cell * RACGPU_NOUT + RACGPU_O_T_END] = out_c[(size_t)f * RACGPU_NOUT + RACGPU_O_T_END];
       quality[cell] = quality_c[f];
       if (useful) {
         t_final[cell] = t_final_c[f];
