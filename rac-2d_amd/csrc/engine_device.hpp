@@ -43,6 +43,18 @@ RG_DEV void bstore_f64(rsrc_t r, int voff, int soff, double v) {
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
 }
+// The same for a wave's big private streams (rate vector, P, L, U), with their own cache-policy switch.  RG_STREAM_AUX: 0 = default
+// policy, 2 = nt.  Measured on the configs[2] workload (round 2): nt on all of them is 22 % SLOWER (10.98 s against 9.00 s per
+// pass): the left-looking LU reads back columns it has just written, and the solves follow a factorisation closely enough to
+// find part of L and U still in L2.
+#ifndef RG_STREAM_AUX
+#define RG_STREAM_AUX 0
+#endif
+RG_DEV double sload_f64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, RG_STREAM_AUX)); }
+RG_DEV void sstore_f64(rsrc_t r, int voff, int soff, double v) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, RG_STREAM_AUX);
+}
 RG_DEV double uniform_d(double v) {
   union { double d; int i[2]; } u; u.d = v;
   u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
@@ -238,14 +250,14 @@ RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double ns
   uint64_t w0[D], w1[D], w2[D];
   double kk[D];
 #pragma unroll
-  for (int s = 0; s < D - 1; ++s) { w0[s] = bload_u64(bW0, l8, s * 512); w1[s] = bload_u64(bW1, l8, s * 512); w2[s] = bload_u64(bW2, l8, s * 512); kk[s] = bload_f64(bK, l8, s * 512); }
+  for (int s = 0; s < D - 1; ++s) { w0[s] = bload_u64(bW0, l8, s * 512); w1[s] = bload_u64(bW1, l8, s * 512); w2[s] = bload_u64(bW2, l8, s * 512); kk[s] = sload_f64(bK, l8, s * 512); }
   for (int r0 = 0; r0 < N.nR; r0 += 64 * D) {
 #pragma unroll
     for (int s = 0; s < D; ++s) {
       const int rb = r0 + 64 * s; // rows rb >= nR are padding (kind 0, no targets)
       {
         const int nx = (rb + 64 * (D - 1)) * 8, sl = (s + D - 1) % D;
-        w0[sl] = bload_u64(bW0, l8, nx); w1[sl] = bload_u64(bW1, l8, nx); w2[sl] = bload_u64(bW2, l8, nx); kk[sl] = bload_f64(bK, l8, nx);
+        w0[sl] = bload_u64(bW0, l8, nx); w1[sl] = bload_u64(bW1, l8, nx); w2[sl] = bload_u64(bW2, l8, nx); kk[sl] = sload_f64(bK, l8, nx);
       }
       const uint64_t c0 = w0[s], c1 = w1[s], c2 = w2[s];
       const double k = kk[s];
@@ -309,7 +321,7 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
 #pragma unroll
   for (int s = 0; s < DT; ++s) tw[s] = bload_u64(bT, l8, s * 512);
 #pragma unroll
-  for (int s = 0; s < DR; ++s) rk[s] = bload_f64(bK, (int)(tw[s] & 0xffff) * 8, 0);
+  for (int s = 0; s < DR; ++s) rk[s] = sload_f64(bK, (int)(tw[s] & 0xffff) * 8, 0);
   uint64_t slot = bload_u64(bS, l8, 0), slot_nx = bload_u64(bS, l8, 512);
   int pass = 0;
   double sum = 0.0;
@@ -320,7 +332,7 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
     for (int s = 0; s < U; ++s) {
       const int r = r0 + s;
       tw[(s + DT) % U] = bload_u64(bT, l8, (r + DT) * 512);
-      rk[(s + DR) % U] = bload_f64(bK, (int)(tw[(s + DR) % U] & 0xffff) * 8, 0);
+      rk[(s + DR) % U] = sload_f64(bK, (int)(tw[(s + DR) % U] & 0xffff) * 8, 0);
       const uint64_t term = tw[s];
       if (term != ~0ull) sum += dev_dflux(term, rk[s], r_C, nsite, y);
       if (__builtin_amdgcn_readlane((int)fl, r & 63)) { // the pass is complete: every lane stores its entry
@@ -328,7 +340,7 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
           double p = sum * con;
           if (add_identity && ((slot >> 48) & 1ull)) p = p + 1.0;
           const int dest = PERMUTED ? (int)((slot >> 24) & 0xffffff) : (int)(slot & 0xffffff);
-          bstore_f64(bP, dest * 8, 0, p);
+          sstore_f64(bP, dest * 8, 0, p);
         }
         sum = 0.0; ++pass;
         slot = slot_nx; slot_nx = bload_u64(bS, l8, (pass + 1) * 512);
@@ -382,7 +394,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   LuCol nxc = load_col(0), nx2 = load_col(1), cur = nxc; // extents are fetched two work items ahead (scalar loads; the list is padded by two)
   unsigned long long nx_dq; double nx_pv; uint16_t nx_pr, nx_fu, nx_fl, cu_fu = 0, cu_fl = 0;
   auto prefetch_col = [&]() {
-    nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = bload_f64(bP, l8, nxc.p0 * 8); nx_pr = bload_u16(bProw, l2, nxc.p0 * 2);
+    nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = sload_f64(bP, l8, nxc.p0 * 8); nx_pr = bload_u16(bProw, l2, nxc.p0 * 2);
     nx_fu = bload_u16(bUrow, l2, nxc.u0 * 2); nx_fl = bload_u16(bLrow, l2, nxc.lc0 * 2);
   };
   prefetch_col();
@@ -404,7 +416,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     nxc = nx2; nx2 = load_col(widx + 2);
     prefetch_col();
     if (lane < cur.p1 - cur.p0) wv[pr] = pv;
-    for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[bload_u16(bProw, q * 2, 0)] = bload_f64(bP, q * 8, 0); // rare: > 64 entries
+    for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[bload_u16(bProw, q * 2, 0)] = sload_f64(bP, q * 8, 0); // rare: > 64 entries
     lds_sync();
     RG_TICK(c_scatter)
     constexpr int D = kLuDepth;
@@ -424,7 +436,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     const int tq_ = min((tt), nk - 1);                                                                             \
     a[S] = __builtin_amdgcn_readlane(dhi, tq_);                                                                    \
     z[S] = (__builtin_amdgcn_readlane(dlo, tq_) >> 16) & 0x3fff; /* rows in this piece of the L column (<= 64) */  \
-    i[S] = bload_u16(bLrow, l2, a[S] * 2); l[S] = bload_f64(bL, l8, a[S] * 8);                                     \
+    i[S] = bload_u16(bLrow, l2, a[S] * 2); l[S] = sload_f64(bL, l8, a[S] * 8);                                     \
   }
 #pragma unroll
       for (int s = 0; s < D - 1; ++s) { RG_LU_ISSUE(s, s) __builtin_amdgcn_sched_barrier(0); } // keep the issue order: data returns in order
@@ -453,8 +465,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   // U part of the current column with rows < uend_rect: final after the LDS pivots; scaled and stored
   auto store_u = [&](double *wv, int uend) {
     int q = cur.u0 + lane;
-    if (q < uend) { const int k = cu_fu; bstore_f64(bU, l8, cur.u0 * 8, wv[k] * dl[k]); wv[k] = 0.0; }
-    for (q += 64; q < uend; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); bstore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
+    if (q < uend) { const int k = cu_fu; sstore_f64(bU, l8, cur.u0 * 8, wv[k] * dl[k]); wv[k] = 0.0; }
+    for (q += 64; q < uend; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); sstore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
   };
 
   // ---- column j, last part: pivot, scaled U and L columns to HBM, work column back to zero ------------------------
@@ -465,13 +477,13 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     const int ku = hasU ? (int)cu_fu : j, il = hasL ? (int)cu_fl : j;
     const double uv = wv[ku], dk = dl[ku], lv = wv[il];
     lds_order();
-    if (hasU) { bstore_f64(bU, l8, cur.u0 * 8, uv * dk); wv[ku] = 0.0; }
-    for (int q = cur.u0 + 64 + lane; q < cur.u1; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); bstore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
+    if (hasU) { sstore_f64(bU, l8, cur.u0 * 8, uv * dk); wv[ku] = 0.0; }
+    for (int q = cur.u0 + 64 + lane; q < cur.u1; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); sstore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
     if (lane == 0) { Dinv[j] = dinv; dl[j] = dinv; wv[j] = 0.0; }
-    if (hasL) { bstore_f64(bL, l8, cur.lc0 * 8, lv * dinv); wv[il] = 0.0; }
-    for (int q = cur.lc0 + 64 + lane; q < cur.lc1; q += 64) { const int i = bload_u16(bLrow, q * 2, 0); bstore_f64(bL, q * 8, 0, wv[i] * dinv); wv[i] = 0.0; }
+    if (hasL) { sstore_f64(bL, l8, cur.lc0 * 8, lv * dinv); wv[il] = 0.0; }
+    for (int q = cur.lc0 + 64 + lane; q < cur.lc1; q += 64) { const int i = bload_u16(bLrow, q * 2, 0); sstore_f64(bL, q * 8, 0, wv[i] * dinv); wv[i] = 0.0; }
     wave_sync(); // L, U, Dinv of this column are read back from HBM by later columns
     RG_TICK(c_fin)
   };
@@ -492,7 +504,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
       const unsigned long long e = bload_u64(bLd, l8, q0 * 8);
       if (q0 + lane < N.nleaf) {
         const int jj = (int)(e >> 32);
-        const double d = bload_f64(bP, (int)(e & 0xfffff) * 8, 0);
+        const double d = sload_f64(bP, (int)(e & 0xfffff) * 8, 0);
         if (d == 0.0) ok = false;
         const double dinv = 1.0 / d;
         Dinv[jj] = dinv; dl[jj] = dinv;
@@ -502,7 +514,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     for (int q0 = 0; q0 < N.nleaf_ent; q0 += 64) {
       const unsigned long long e = bload_u64(bLe, l8, q0 * 8);
       if (q0 + lane < N.nleaf_ent)
-        bstore_f64(bL, (int)((e >> 20) & 0xfffff) * 8, 0, bload_f64(bP, (int)(e & 0xfffff) * 8, 0) * dl[(int)(e >> 40)]);
+        sstore_f64(bL, (int)((e >> 20) & 0xfffff) * 8, 0, sload_f64(bP, (int)(e & 0xfffff) * 8, 0) * dl[(int)(e >> 40)]);
     }
     wave_sync();
     RG_TICK(c_fin)
@@ -537,7 +549,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
     const int k = min((kb_) + u, max(j - 1, ns)), kk = k - ns;                                                    \
     const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - k - 1) * 8; /* byte offset of L(0, k): L(row, k) sits row*8 further */ \
-    const double va = bload_f64(bL, rA8, cb), vb = bload_f64(bL, rB8, cb); /* unconditional: rows outside the column read neighbouring entries */ \
+    const double va = sload_f64(bL, rA8, cb), vb = sload_f64(bL, rB8, cb); /* unconditional: rows outside the column read neighbouring entries */ \
     LA[u] = (rowA > k && rowA < n) ? va : 0.0;                                                                    \
     LB[u] = (rowB > k && rowB < n) ? vb : 0.0;                                                                    \
   }
@@ -584,10 +596,10 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
         lds_sync(); // dl[jc] is read below by the lanes of later columns
         const int ub = ((nzus + kk * (kk - 1) / 2) - ns) * 8;                    // byte offset of U(0, jc): rows ns <= row < jc are stored
         const int lb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - jc - 1) * 8; // byte offset of L(0, jc): rows > jc are stored
-        if (rowA < jc) bstore_f64(bU, rA8, ub, wA[c] * dl[rowA]);
-        else if (rowA > jc && rowA < n) bstore_f64(bL, rA8, lb, lA);
-        if (rowB < jc) bstore_f64(bU, rB8, ub, wB[c] * dl[rowB]);
-        else if (rowB > jc && rowB < n) bstore_f64(bL, rB8, lb, lB);
+        if (rowA < jc) sstore_f64(bU, rA8, ub, wA[c] * dl[rowA]);
+        else if (rowA > jc && rowA < n) sstore_f64(bL, rA8, lb, lA);
+        if (rowB < jc) sstore_f64(bU, rB8, ub, wB[c] * dl[rowB]);
+        else if (rowB > jc && rowB < n) sstore_f64(bL, rB8, lb, lB);
       }
     }
     wave_sync(); // L, U, Dinv of these columns are read back from HBM by later columns
@@ -612,14 +624,14 @@ RG_DEV void dev_tri_sweep(const uint32_t *__restrict__ rc, const double *__restr
   const rsrc_t brc = mkbuf(rc), bval = mkbuf(val);
   const int l4 = lane * 4, l8 = lane * 8;
 #pragma unroll
-  for (int s = 0; s < D - 1; ++s) { r[s] = bload_u32(brc, l4, s * 256); v[s] = bload_f64(bval, l8, s * 512); }
+  for (int s = 0; s < D - 1; ++s) { r[s] = bload_u32(brc, l4, s * 256); v[s] = sload_f64(bval, l8, s * 512); }
   double x = 0.0;
   bool have = false; // x already holds this chunk's x[col] (read while the previous chunk of the same level was applied)
   for (int c = 0; c < nchunk; c += D) { // nchunk is a multiple of D (null chunks at the end)
 #pragma unroll
     for (int s = 0; s < D; ++s) {
       const int sl = (s + D - 1) % D; // the set applied one sub-step ago is free again
-      r[sl] = bload_u32(brc, l4, (c + s + D - 1) * 256); v[sl] = bload_f64(bval, l8, (c + s + D - 1) * 512);
+      r[sl] = bload_u32(brc, l4, (c + s + D - 1) * 256); v[sl] = sload_f64(bval, l8, (c + s + D - 1) * 512);
       const uint32_t wd = r[s], wn = r[(s + 1) % D];
       const int row = (int)(wd & 1023u), col = (int)((wd >> 10) & 1023u);
       const bool cont = (__builtin_amdgcn_readfirstlane((int)wd) >> 20) & 1;
@@ -671,7 +683,7 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
     const int kc_ = min((k_), n - 2); /* (not "k": the argument may mention the caller's k) */                     \
     const int kk = kc_ - ns;                                                                                       \
     const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - kc_ - 1) * 8; /* byte offset of L(0, k); rows k < row < n are stored */ \
-    la[S] = bload_f64(bL, rA8, cb); lb[S] = bload_f64(bL, rB8, cb); /* rows outside the column read neighbouring entries */ \
+    la[S] = sload_f64(bL, rA8, cb); lb[S] = sload_f64(bL, rB8, cb); /* rows outside the column read neighbouring entries */ \
   }
 #pragma unroll
     for (int s = 0; s < D; ++s) RG_DS_LOAD(s, ns + s)
@@ -697,7 +709,7 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
   {                                                                                                               \
     const int kk = max((k_), ns + 1) - ns;                                                                         \
     const int cb = ((nzus + kk * (kk - 1) / 2) - ns) * 8; /* byte offset of U(0, k); rows ns <= row < k are stored */ \
-    ua[S] = bload_f64(bU, rA8, cb); ub[S] = bload_f64(bU, rB8, cb);                                                \
+    ua[S] = sload_f64(bU, rA8, cb); ub[S] = sload_f64(bU, rB8, cb);                                                \
   }
 #pragma unroll
     for (int s = 0; s < D; ++s) RG_DS_LOAD(s, n - 1 - s)

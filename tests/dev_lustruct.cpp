@@ -49,6 +49,23 @@ int main(int argc, char **argv) {
   // rows of L21 nnz per tail row
   std::vector<int> rown(n, 0); for (int k = 0; k < ns; ++k) for (int t = S.Lcolptr[k]; t < S.Lcolend[k]; ++t) rown[S.Lrow[t]]++;
   printf("L21 nnz per tail row:"); for (int i = ns; i < n; ++i) printf(" %d", rown[i]); printf("\n");
+  {
+    std::vector<int> l11len(ns, 0), l21len(ns, 0);
+    for (int k = 0; k < ns; ++k) for (int t = S.Lcolptr[k]; t < S.Lcolend[k]; ++t) (S.Lrow[t] >= ns ? l21len[k] : l11len[k])++;
+    long pairs11 = 0, pairs = 0, pairs21 = 0;
+    for (int j = ns; j < n; ++j) for (int q = S.Ucolptr[j]; q < S.Ucolend[j]; ++q) { pairs++; if (l11len[S.Urow[q]]) pairs11++; if (l21len[S.Urow[q]]) pairs21++; }
+    printf("trailing (j,k) pairs %ld, with nonempty L11 column %ld, with nonempty L21 column %ld\n", pairs, pairs11, pairs21);
+    for (int G : {2, 3, 4, 8, 16}) {
+      long tot = 0, totmadd = 0; int ngroups = 0;
+      for (int j0 = ns; j0 < n; j0 += G) {
+        std::vector<char> in(ns, 0);
+        for (int j = j0; j < std::min(n, j0 + G); ++j) for (int q = S.Ucolptr[j]; q < S.Ucolend[j]; ++q) in[S.Urow[q]] = 1;
+        for (int k = 0; k < ns; ++k) if (in[k]) { tot++; totmadd += l21len[k]; }
+        ngroups++;
+      }
+      printf("G=%d: groups %d, sum of union sizes %ld (x G = %ld slots vs %ld real pairs), L21 entries loaded %ld\n", G, ngroups, tot, tot * G, pairs, totmadd);
+    }
+  }
   return 0;
 }
 // hipcc -O2 -std=c++17 tests/dev_lustruct.cpp rac-2d_amd/csrc/network.o -o build/dev_lustruct
