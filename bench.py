@@ -78,43 +78,52 @@ def _read_sections(fn):
     return {k: np.array(v) for k, v in d.items()}
 
 
-def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS):
+def run_reference(sample, network, initial, params, rtol=None):
+    """oracle/_ref/ref_driver on the rows of `sample`, one process per host core; returns (list of section dicts, seconds, cores)
+    or (None, 0, cores) when the binary is absent or fails."""
+    cores = min(os.cpu_count() or 1, 16)
+    driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(driver):
+        return None, 0.0, cores
+    with tempfile.TemporaryDirectory() as td:
+        procs, dirs = [], []
+        t0 = time.perf_counter()
+        for w in range(cores):
+            part = sample[w::cores]
+            if len(part) == 0:
+                continue
+            d = os.path.join(td, "w%d" % w)
+            os.makedirs(d)
+            dirs.append((w, d, len(part)))
+            np.savetxt(os.path.join(d, "cells.txt"), part, fmt="%.17e")
+            with open(os.path.join(d, "run.nml"), "w") as f:
+                f.write("&ref_run\n chem_dir='%s/'\n network='%s'\n initial='%s'\n out_dir='%s'\n cell_file='%s'\n ncell=%d\n"
+                        " rtol=%.17e\n atol=%.17e\n dt_first_step=%.17e\n ratio_tstep=%.17e\n t_max=%.17e\n mxstep=%d\n"
+                        " steps_reset=%d\n dump_jac=0\n solve=1\n/\n" % (
+                            DATA, network, initial, d, os.path.join(d, "cells.txt"), len(part), rtol or params.RTOL, params.ATOL,
+                            params.dt_first_step, params.ratio_tstep, params.t_max, params.mxstep_per_interval,
+                            params.steps_reset_solver))
+            procs.append(subprocess.Popen([driver, os.path.join(d, "run.nml")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        ok = all(p.wait() == 0 for p in procs)
+        dt = time.perf_counter() - t0
+        if not ok:
+            return None, dt, cores
+        ref = {}
+        for w, d, m in dirs:
+            for k in range(m):
+                ref[w + k * cores] = _read_sections(os.path.join(d, "cell_%04d.txt" % (k + 1)))
+    return [ref[k] for k in range(len(sample))], dt, cores
+
+
+def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS, tight=None):
     """The reference's own Fortran path (oracle/_ref/ref_driver, built from the unmodified sources in the build container)
     on a bounded sample of the same cells, one process per host core.  Returns (cpu_baseline, parity).  Falls back to the
     C restatement (kind "port", single thread).  Baseline and checker only: nothing here is on the product path."""
-    cores = min(os.cpu_count() or 1, 16)
     sample = cells[sample_idx]
     nsample = len(sample)
-    driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    ref = None
-    if os.path.exists(driver):
-        with tempfile.TemporaryDirectory() as td:
-            procs, dirs = [], []
-            t0 = time.perf_counter()
-            for w in range(cores):
-                part = sample[w::cores]
-                if len(part) == 0:
-                    continue
-                d = os.path.join(td, "w%d" % w)
-                os.makedirs(d)
-                dirs.append((w, d, len(part)))
-                np.savetxt(os.path.join(d, "cells.txt"), part, fmt="%.17e")
-                with open(os.path.join(d, "run.nml"), "w") as f:
-                    f.write("&ref_run\n chem_dir='%s/'\n network='%s'\n initial='%s'\n out_dir='%s'\n cell_file='%s'\n ncell=%d\n"
-                            " rtol=%.17e\n atol=%.17e\n dt_first_step=%.17e\n ratio_tstep=%.17e\n t_max=%.17e\n mxstep=%d\n"
-                            " steps_reset=%d\n dump_jac=0\n solve=1\n/\n" % (
-                                DATA, network, initial, d, os.path.join(d, "cells.txt"), len(part), params.RTOL, params.ATOL,
-                                params.dt_first_step, params.ratio_tstep, params.t_max, params.mxstep_per_interval,
-                                params.steps_reset_solver))
-                procs.append(subprocess.Popen([driver, os.path.join(d, "run.nml")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
-            ok = all(p.wait() == 0 for p in procs)
-            dt = time.perf_counter() - t0
-            if ok:
-                ref = {}
-                for w, d, m in dirs:
-                    for k in range(m):
-                        ref[w + k * cores] = _read_sections(os.path.join(d, "cell_%04d.txt" % (k + 1)))
-        if ref is not None:
+    ref, dt, cores = run_reference(sample, network, initial, params)
+    if ref is not None:
+        if True:
             steps = float(np.sum(gpu["nst"][sample_idx]))
             base = {"value": steps / dt, "unit": "cell-steps/s", "cores": cores, "kind": "reference",
                     "sample": "%d cells of the same batch (every %d-th), reference Fortran/DLSODES binary, %d processes, %.1f s wall; "
@@ -136,6 +145,16 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                       "t_final_equal": tf_eq, "quality_equal": q_eq,
                       "note": "at RTOL 1e-4 the reference moves by 1e-5...1e-3 against its own 1-ulp-perturbed twin (tests/golden yend_ulp); "
                               "the RTOL 1e-8 pin (<= 2e-6) is tests/test_gpu_parity.py::test_tight_tolerance_run_matches_the_reference_truth"}
+            if tight is not None:  # the same comparison where trajectory noise does not limit it: RTOL 1e-8 on both sides
+                tidx, gy = tight
+                tref, tdt, _ = run_reference(cells[tidx], network, initial, params, rtol=1e-8)
+                if tref is not None:
+                    te = []
+                    for k in range(len(tidx)):
+                        yr = tref[k]["yend"][:nS]; m = yr >= 1e-6
+                        te.append(float(np.max(np.abs(gy[k][m] - yr[m]) / yr[m])))
+                    parity["tight"] = {"rtol": 1e-8, "cells": len(tidx), "max_rel_err": float(np.max(te)), "median_rel_err": float(np.median(te)),
+                                       "reference_seconds": tdt}
             return base, parity
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_ctypes as O
@@ -341,7 +360,14 @@ def main():
             nsample = min(ncell, 16 * cores)
             sample_idx = np.arange(nsample) * (ncell // nsample) + (ncell // nsample) // 2  # spread over the whole batch
             gpu = {"y": y_d.cpu().numpy(), "t_final": tfin_d.cpu().numpy(), "quality": qual, "nst": stats[:, 0]}
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cells_h, sample_idx, network, initial, params, gpu, nS)
+            tidx = sample_idx[::max(1, nsample // 32)][:32]
+            p8 = R.default_params()
+            for f in ("ATOL", "t_max", "dt_first_step", "ratio_tstep", "mxstep_per_interval", "steps_reset_solver"):
+                setattr(p8, f, getattr(params, f))
+            p8.RTOL = 1e-8
+            net.set_cost_hints(None)
+            gy = net.evol_solve_batch(p8, cells_h[tidx], yinit_h[tidx])["y"]
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cells_h, sample_idx, network, initial, params, gpu, nS, tight=(tidx, gy))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

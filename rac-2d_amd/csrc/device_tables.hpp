@@ -15,9 +15,19 @@ constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K
 // extents of column j in the U, L and P storage; ur = end of the U entries with rows < ns (the pivots applied through
 // LDS); [d0, d1) = the column's slice of the pivot descriptor stream
 struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, j, pad[6]; }; // j = the column this work item factors
-constexpr int kJacUnroll = 8; // rows of the Jacobian term stream per unrolled step (the stream is padded to a multiple)
-constexpr int kSweepDepth = 4; // chunks of a triangular-solve stream in flight; the schedules are padded to a multiple
-constexpr int kLuDepth = 4; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
+#ifndef RG_JAC_UNROLL
+#define RG_JAC_UNROLL 8
+#endif
+#ifndef RG_SWEEP_DEPTH
+#define RG_SWEEP_DEPTH 8
+#endif
+#ifndef RG_LU_DEPTH
+#define RG_LU_DEPTH 6
+#endif
+// depths and group sizes below: measured on the configs[2] scan, round 2 (profiles/r2_tuning.txt)
+constexpr int kJacUnroll = RG_JAC_UNROLL; // rows of the Jacobian term stream per unrolled step (the stream is padded to a multiple)
+constexpr int kSweepDepth = RG_SWEEP_DEPTH; // chunks of a triangular-solve stream in flight; the schedules are padded to a multiple
+constexpr int kLuDepth = RG_LU_DEPTH; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
 
 struct DevNet {
   int nS, nR, npad;          // npad = nS rounded up to 64

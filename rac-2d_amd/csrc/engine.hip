@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   long long cyc[4] = {0, 0, 0, 0}, c_lu = 0, c_solve = 0;
   for (int r = 0; r < repeat; ++r) {
     const long long t0 = (long long)__builtin_readcyclecounter();
-    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.y, lane, cyc);
+    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.y, lane, cyc, v.wx + nlds);
     const long long t1 = (long long)__builtin_readcyclecounter();
     for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
     dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
@@ -746,7 +746,7 @@ int racgpu_set_stream(racgpu_network *h, void *s) {
   return 0;
 }
 
-static size_t lds_bytes(const DevNet &dn) { return (size_t)3 * ((dn.nS + 1) & ~1) * sizeof(double); }
+static size_t lds_bytes(const DevNet &dn) { return (size_t)3 * ((dn.nS + 1) & ~1) * sizeof(double) + 64 * sizeof(double); } // + one spare double per lane behind the last vector
 
 int racgpu_rates(racgpu_network *h, const racgpu_params *p, const double *cells, int64_t ncell, double *rates) {
   if (!h) return fail("null network");
@@ -865,7 +865,9 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
   const size_t nS = h->dn.nS;
   const size_t lds = lds_bytes(h->dn);
   // waves per CU: 3 per SIMD by registers (<= 168 VGPRs, tests/test_build_resources.py), and what the LDS holds (512 B static)
-  const long per_cu = std::max<long>(1, std::min<long>(12, (long)(160 * 1024 / (lds + 512))));
+  long cap = 12;
+  if (const char *e = std::getenv("RACGPU_WAVES_PER_CU")) cap = std::max(1, std::atoi(e)); // developer aid
+  const long per_cu = std::max<long>(1, std::min<long>(cap, (long)(160 * 1024 / (lds + 512))));
   const long slots = std::min<long>(ncell, per_cu * h->cu_count);
   const long chunk_cells = std::max<long>(slots, std::min<long>(ncell, (long)(8e9 / (8.0 * h->dn.nR)))); // <= 8 GB of rates
   h->ensure_workspace(slots, chunk_cells);

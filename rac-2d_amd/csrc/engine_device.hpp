@@ -370,8 +370,12 @@ RG_DEV void lds_sync() {
 // w is the wave's LDS work column.  Returns false on an exactly zero pivot (DPRJS IERPJ = 1).
 // Everything a column needs first (its extents, its P entries, its pivot descriptors, the row lists of its U and
 // L parts) is fetched while the previous column is being worked on.
+#ifndef RG_BRANCHFREE
+#define RG_BRANCHFREE 1
+#endif
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
-                   double *__restrict__ Dinv, double *w, double *dl, int lane, long long *cyc = nullptr) {
+                   double *__restrict__ Dinv, double *w, double *dl, int lane, long long *cyc = nullptr, double *dmy = nullptr) {
+  // dmy: 64 spare LDS doubles, one per lane (RG_BRANCHFREE)
   // w: LDS work column;
   // dl: LDS copy of D^-1 (the U columns are scaled by it, and a gather from LDS beats one from HBM)
   bool ok = true;
@@ -454,7 +458,12 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
           src.d = tvv;
           tv.w[0] = __builtin_amdgcn_readlane(src.w[0], tt);
           tv.w[1] = __builtin_amdgcn_readlane(src.w[1], tt);
+#if RG_BRANCHFREE
+          // no exec-masked branch: lanes past the end of the L column add (a finite product of neighbouring entries) to a slot of their own
+          atomicAdd(lane < z[s] ? &wv[i[s]] : &dmy[lane], -(l[s] * tv.d));
+#else
           if (lane < z[s]) atomicAdd(&wv[i[s]], -(l[s] * tv.d)); // (program order of LDS accesses is kept by the compiler: may-alias)
+#endif
         }
       }
 #undef RG_LU_ISSUE
@@ -523,12 +532,15 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   for (int c = 0; c < N.nwork_sparse; ++c) { rect_phase(c, w); RG_TICK(c_dense) finish(cur.j, w); }
   int j = ns;
 
-  // ---- dense trailing block, G columns at a time (G = 8: every L column of the block is read n/8 times, not n times) ----
+  // ---- dense trailing block, G columns at a time (G = 12: every L column of the block is read n/12 times, not n times) ----
   // After a column's LDS pivots (k < ns) its entries in rows < ns are final and go straight to U; its tail rows
   // (ns+lane, ns+64+lane) move to registers and stay there.  Pivot k >= ns reads its multiplier from the lane that
   // owns row k (v_readlane) and its L column (rows k+1..n-1, contiguous) with one load that serves all G columns.
   // Nothing of this phase touches LDS except the D^-1 copy; results are stored from registers.
-  constexpr int G = 8;
+#ifndef RG_DENSE_G
+#define RG_DENSE_G 12
+#endif
+  constexpr int G = RG_DENSE_G;
   for (; j < n; j += G) {
     const int ng = min(G, n - j);
     double wA[G], wB[G];

@@ -158,7 +158,7 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   {
     const long long t0 = dev_clock();
     long long part[4] = {0, 0, 0, 0};
-    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, part)) s.ierpj = 1;
+    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, part, c.wx + ((c.n + 1) & ~1))) s.ierpj = 1;
     cyc_add(CYC_LU, dev_clock() - t0);
     for (int k = 0; k < 4; ++k) cyc_add(CYC_LU_PART + k, part[k]);
   }

@@ -1,6 +1,12 @@
 ! racgpu_host.f90 -- Fortran host for the batched GPU chemistry solve.
 !
-!   racgpu_host <configure.dat> <cells.txt> <out_prefix>
+!   racgpu_host <configure.dat> <cells.txt> <out_prefix> [nlocal_iter [restart.bin]]
+!
+!   nlocal_iter  (default 1) a_disk_iter_params%nlocal_iter of the reference's &iteration_configure: > 1 runs calc_this_cell's
+!                local-iteration loop (retries from t_final with looser tolerance policies, reference src/disk.f90:1651-1791)
+!                through racgpu_calc_cells
+!   restart.bin  a chemical_data_iter_NNNN.bin of a previous run (reference src/data_dump.f90:88-162, read back as
+!                back_cells_chemical_data_load does): the cells start from its abundances instead of the initial-abundance file
 !
 ! Plays the part of rac-2d's cell sweep (do_chemical_stuff -> calc_this_cell, reference src/disk.f90:864-938,
 ! 1629-1801) for a table of frozen per-cell input records: reads the reference's own `&chemistry_configure`
@@ -9,7 +15,8 @@
 !   <out_prefix>.bin : direct-access records in the layout of the reference's chemical_data_iter_NNNN.bin
 !                      (record i = cell i = abundances(nSpecies), col_den_toStar(10), col_den_toISM(10), all f64;
 !                      reference src/data_dump.f90:88-162; the 20 column densities belong to the caller: zeros)
-!   <out_prefix>.dat : one row per cell: t_final, quality, NST, then abundances in ES14.5E3 under an A14 header
+!   <out_prefix>.dat : one row per cell: t_final, quality, NST, local iterations used, R_H2_form_rate_coeff, n_mol_on_grain (the two
+!                      fields of the cell record the path writes), then abundances in ES14.5E3 under an A14 header
 !                      (the trailing columns of the reference's iter_NNNN.dat, src/disk.f90:2749-2750, 3072)
 !   with flag_chem_evol_save = .true. in the namelist, per cell i also
 !   <out_prefix>_cellNNNNNN_<chem_evol_save_filename> : the time series chem_evol_solve writes while it integrates
@@ -19,7 +26,10 @@ program racgpu_host
   use, intrinsic :: iso_c_binding
   use racgpu
   implicit none
-  character(len=512) :: f_conf, f_cells, prefix, path
+  character(len=512) :: f_conf, f_cells, prefix, path, f_restart, argbuf
+  integer :: nlocal_iter
+  real(c_double), allocatable, target :: cell_out(:, :)
+  real(c_double), allocatable :: col20(:)
   character(kind=c_char), dimension(32) :: nbuf
   character(len=12), allocatable :: names(:)
   type(c_ptr) :: net
@@ -42,6 +52,13 @@ program racgpu_host
   call get_command_argument(1, f_conf)
   call get_command_argument(2, f_cells)
   call get_command_argument(3, prefix)
+  nlocal_iter = 1
+  f_restart = ''
+  if (command_argument_count() >= 4) then
+    call get_command_argument(4, argbuf)
+    read(argbuf, *) nlocal_iter
+  end if
+  if (command_argument_count() >= 5) call get_command_argument(5, f_restart)
 
   open(newunit=fu, file=trim(f_conf), status='old', action='read')
   call chemistry_configure_read(fu, ios)
@@ -97,16 +114,36 @@ program racgpu_host
   close(fu)
 
   rc = racgpu_init_abundances(net, y0, cells, int(ncell, c_int64_t), y)
+  allocate(cell_out(RACGPU_NOUT, ncell), col20(20))
+  cell_out = 0D0
+  if (len_trim(f_restart) > 0) then ! use_backup_chemical_data: record i = cell i = abundances(nSpecies), 20 column densities
+    inquire(iolength=reclen) y(:, 1), col20
+    open(newunit=fu, file=trim(f_restart), access='direct', form='unformatted', recl=reclen, status='old', action='read')
+    do i = 1, ncell
+      read(fu, rec=i) y(:, i), col20
+    end do
+    close(fu)
+    write(*, '(A, A)') 'Abundances taken from ', trim(f_restart)
+  end if
   prec = c_null_ptr; ptouts = c_null_ptr
   n_record = racgpu_n_record(p, 0D0, p%t_max)
   if (chemsol_params%flag_chem_evol_save) then ! chemsol_stor%record / %touts of every cell (1.2 MB per cell)
     allocate(record(nS + 1, n_record, ncell), touts(n_record, ncell))
     prec = c_loc(record); ptouts = c_loc(touts)
   end if
-  rc = racgpu_solve_batch(net, p, int(ncell, c_int64_t), c_loc(cells), c_loc(y), c_loc(t_final), c_loc(quality), &
-                          c_loc(stats), prec, ptouts, RACGPU_MEM_HOST)
+  if (nlocal_iter > 1) then
+    if (chemsol_params%flag_chem_evol_save) then
+      write(*, '(A)') 'racgpu_host: flag_chem_evol_save needs nlocal_iter = 1 (the reference overwrites the file in every local iteration)'
+      stop 1
+    end if
+    rc = racgpu_calc_cells(net, p, int(nlocal_iter, c_int32_t), int(ncell, c_int64_t), c_loc(cells), c_loc(y), c_loc(t_final), &
+                           c_loc(quality), c_loc(stats), c_loc(cell_out), RACGPU_MEM_HOST)
+  else
+    rc = racgpu_evol_solve_batch(net, p, int(ncell, c_int64_t), c_loc(cells), c_loc(y), c_null_ptr, c_null_ptr, c_loc(t_final), &
+                                 c_loc(quality), c_loc(stats), prec, ptouts, c_loc(cell_out), 0_c_int, RACGPU_MEM_HOST)
+  end if
   if (rc /= 0) then
-    write(*, '(A)') 'racgpu_solve_batch: ' // trim(racgpu_error_string())
+    write(*, '(A)') 'racgpu solve: ' // trim(racgpu_error_string())
     stop 1
   end if
   write(*, '(A, I8, A, F10.2, A, I12)') 'Solved ', ncell, ' cells; kernel ', racgpu_last_kernel_ms(net), ' ms; total steps ', sum(stats(1, :))
@@ -119,11 +156,12 @@ program racgpu_host
   end do
   close(fu)
   open(newunit=fu, file=trim(prefix) // '.dat', status='replace')
-  write(fmt, '("(", I4, "A14)")') nS + 3
-  write(fu, fmt) '  t_final     ', '  quality     ', '  NST         ', (adjustr(names(i) // '  '), i = 1, nS)
-  write(fmt, '("(ES14.5E3, 2I14, ", I4, "ES14.5E3)")') nS
+  write(fmt, '("(", I4, "A14)")') nS + 6
+  write(fu, fmt) '  t_final     ', '  quality     ', '  NST         ', '  local_iter  ', '  R_H2_form   ', '  n_mol_grain ', &
+                 (adjustr(names(i) // '  '), i = 1, nS)
+  write(fmt, '("(ES14.5E3, 3I14, ", I4, "ES14.5E3)")') nS + 2
   do i = 1, ncell
-    write(fu, fmt) t_final(i), quality(i), int(stats(1, i)), y(:, i)
+    write(fu, fmt) t_final(i), quality(i), int(stats(1, i)), int(stats(18, i)), cell_out(1, i), cell_out(2, i), y(:, i)
   end do
   close(fu)
   if (chemsol_params%flag_chem_evol_save) then

@@ -30,9 +30,18 @@ def test_fortran_host_matches_reference(tmp_path, racgpu):
         floor = major_relerr(g["yend_ulp"][c][:nS], ref)
         assert major_relerr(rec[c, :nS], ref) <= max(1e-4, 3 * floor)
     rows = open(tmp_path / "out.dat").read().splitlines()
-    assert len(rows) == 3 and len(rows[0]) == 14 * (nS + 3)
-    hdr = [rows[0][14 * k:14 * (k + 1)].strip() for k in range(nS + 3)]
-    assert hdr[3:] == list(g["species"])
+    assert len(rows) == 3 and len(rows[0]) == 14 * (nS + 6)
+    hdr = [rows[0][14 * k:14 * (k + 1)].strip() for k in range(nS + 6)]
+    assert hdr[6:] == list(g["species"])
+    # restart from the .bin just written (the reference's use_backup_chemical_data path), local-iteration loop on: cells
+    # that finished with quality 0 stay as they are handed in (t0 = 0 again, so this is a second full run from the end state)
+    out2 = subprocess.run([HOST, os.path.join(ROOT, "tests", "fortran_host", "configure_chemistry.dat"), str(tmp_path / "cells.txt"),
+                           str(tmp_path / "out2"), "4", str(tmp_path / "out.bin")], cwd=ROOT, capture_output=True, text=True)
+    assert out2.returncode == 0 and "Abundances taken from" in out2.stdout, out2.stdout + out2.stderr
+    rec2 = np.fromfile(tmp_path / "out2.bin", dtype=np.float64).reshape(2, nS + 20)
+    assert np.isfinite(rec2).all() and rec2.shape == rec.shape
+    row2 = open(tmp_path / "out2.dat").read().splitlines()[1]
+    assert int(row2[14 * 3:14 * 4]) == 1  # one local iteration sufficed
 
 
 @pytest.mark.gpu
