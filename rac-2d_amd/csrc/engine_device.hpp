@@ -373,6 +373,9 @@ RG_DEV void lds_sync() {
 #ifndef RG_BRANCHFREE
 #define RG_BRANCHFREE 1
 #endif
+#ifndef RG_CLAMP_LOADS
+#define RG_CLAMP_LOADS 1
+#endif
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
                    double *__restrict__ Dinv, double *w, double *dl, int lane, long long *cyc = nullptr, double *dmy = nullptr) {
   // dmy: 64 spare LDS doubles, one per lane (RG_BRANCHFREE)
@@ -398,7 +401,12 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   LuCol nxc = load_col(0), nx2 = load_col(1), cur = nxc; // extents are fetched two work items ahead (scalar loads; the list is padded by two)
   unsigned long long nx_dq; double nx_pv; uint16_t nx_pr, nx_fu, nx_fl, cu_fu = 0, cu_fl = 0;
   auto prefetch_col = [&]() {
+#if RG_CLAMP_LOADS
+    const int op8 = min(l8, max(nxc.p1 - nxc.p0 - 1, 0) * 8); // (same clamp for the column's P entries)
+    nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = sload_f64(bP, op8, nxc.p0 * 8); nx_pr = bload_u16(bProw, op8 >> 2, nxc.p0 * 2);
+#else
     nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = sload_f64(bP, l8, nxc.p0 * 8); nx_pr = bload_u16(bProw, l2, nxc.p0 * 2);
+#endif
     nx_fu = bload_u16(bUrow, l2, nxc.u0 * 2); nx_fl = bload_u16(bLrow, l2, nxc.lc0 * 2);
   };
   prefetch_col();
@@ -440,8 +448,17 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     const int tq_ = min((tt), nk - 1);                                                                             \
     a[S] = __builtin_amdgcn_readlane(dhi, tq_);                                                                    \
     z[S] = (__builtin_amdgcn_readlane(dlo, tq_) >> 16) & 0x3fff; /* rows in this piece of the L column (<= 64) */  \
-    i[S] = bload_u16(bLrow, l2, a[S] * 2); l[S] = sload_f64(bL, l8, a[S] * 8);                                     \
+    RG_LU_LOADS(S)                                                                                                 \
   }
+#if RG_CLAMP_LOADS
+  // lanes past the end of the L column re-read its LAST entry instead of whatever follows it: a 512-byte wave load of a column
+  // of 8 entries then touches one cache line instead of eight (the pivot loop alone fetched 2.6x its useful bytes before)
+#define RG_LU_LOADS(S)                                                                                            \
+    { const int o8_ = min(l8, max(z[S] - 1, 0) * 8);                                                               \
+      i[S] = bload_u16(bLrow, o8_ >> 2, a[S] * 2); l[S] = sload_f64(bL, o8_, a[S] * 8); }
+#else
+#define RG_LU_LOADS(S) { i[S] = bload_u16(bLrow, l2, a[S] * 2); l[S] = sload_f64(bL, l8, a[S] * 8); }
+#endif
 #pragma unroll
       for (int s = 0; s < D - 1; ++s) { RG_LU_ISSUE(s, s) __builtin_amdgcn_sched_barrier(0); } // keep the issue order: data returns in order
       for (int t = 0; t < nk; t += D) {
@@ -467,6 +484,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
         }
       }
 #undef RG_LU_ISSUE
+#undef RG_LU_LOADS
     }
     RG_TICK(c_rect)
   };
