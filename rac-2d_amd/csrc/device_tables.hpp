@@ -69,11 +69,6 @@ struct DevNet {
   const unsigned long long *Udesc;
   const LuCol *lucol;        // [nwork+2] the LU's work list (engine.hip, upload): columns with pivots, then the trailing block
   int nwork_sparse, nwork;   // work items with j < ns / in all
-  // trailing columns, rows/pivots < ns in two vectorised phases (network.hpp, struct Symbolic): slot in the wave's Laux copy per
-  // stream position of L; phase-1 steps and entries; the ELL geometry of phase 2
-  const uint16_t *aux_of_L, *ell_k, *ell_row;
-  const int *t1_ptr; const uint32_t *t1_step, *t1_ent;
-  int n11, ell_npass, ell_ti, naux; // naux = n11 + ell_npass*ell_ti*64 doubles of Laux per wave
   const unsigned long long *leaf_diag, *leaf_ent; // pivot-free columns, factored elementwise beforehand
   int nleaf, nleaf_ent;
   int nchunkL, nchunkU;
@@ -106,7 +101,6 @@ struct DevWork { // per-cell workspace, all f64, cell-major
   double *U;       // [ncell][nzu]
   double *Dinv;    // [ncell][npad]
   double *rtol, *atol; // [ncell][npad]
-  double *Laux;    // [ncell][naux] copy of the sparse columns' L entries in the order the trailing-column phases read them
   double *acor, *ewt; // [ncell][npad] accumulated correction and inverse error weights of the step in progress
   double *ygood;   // [ncell][npad] the last record whose T and H2 entries are not NaN (the hand-off record)
   int *counter;    // work queue head

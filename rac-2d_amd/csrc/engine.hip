@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   long long cyc[4] = {0, 0, 0, 0}, c_lu = 0, c_solve = 0;
   for (int r = 0; r < repeat; ++r) {
     const long long t0 = (long long)__builtin_readcyclecounter();
-    dev_lu(N, Pv, Lv, Uv, Dinv, W.Laux + (size_t)cell * N.naux, W.acor + (size_t)cell * N.npad, v.wx, v.y, v.savf, lane, cyc, v.wx + nlds);
+    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.y, lane, cyc, v.wx + nlds);
     const long long t1 = (long long)__builtin_readcyclecounter();
     for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
     dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
   LdsViews v = carve(lds, nlds);
   CellCtx c;
   c.y = v.y; c.savf = v.savf; c.wx = v.wx;
-  c.acor = W.acor + (size_t)slot * N.npad; c.ewt = W.ewt + (size_t)slot * N.npad; c.Laux = W.Laux + (size_t)slot * N.naux;
+  c.acor = W.acor + (size_t)slot * N.npad; c.ewt = W.ewt + (size_t)slot * N.npad;
   c.rates = nullptr; c.yh = W.yh + (size_t)slot * 6 * N.npad; c.Pv = W.P + (size_t)slot * N.nnzJ;
   c.Lv = W.L + (size_t)slot * N.nzl; c.Uv = W.U + (size_t)slot * N.nzu; c.Dinv = W.Dinv + (size_t)slot * N.npad;
   c.rtol = W.rtol + (size_t)slot * N.npad; c.atol = W.atol + (size_t)slot * N.npad;
@@ -497,17 +497,6 @@ void racgpu_network::upload() {
       lc.push_back(lc.empty() ? LuCol{} : lc.back()); lc.push_back(lc.back()); // the column prefetch reads two ahead
       dn.lucol = up(lc);
     }
-    {
-      std::vector<uint16_t> aux(S.aux_of_L.size() + 64, 0);
-      for (size_t q = 0; q < S.aux_of_L.size(); ++q) aux[q] = S.aux_of_L[q] >= 0 ? (uint16_t)S.aux_of_L[q] : (uint16_t)(S.n11 + S.ell_npass * S.ell_ti * 64); // padding -> a spare slot
-      dn.aux_of_L = up(aux);
-      std::vector<uint16_t> ek(S.ell_k); ek.resize(ek.size() + 64, 0);
-      std::vector<uint16_t> er(S.ell_row); er.resize(er.size() + 64, 0xffff);
-      dn.ell_k = up(ek); dn.ell_row = up(er);
-      std::vector<uint32_t> st(S.t1_step), en(S.t1_ent); st.resize(st.size() + 8, 0u); en.resize(en.size() + 64, 0u);
-      dn.t1_ptr = up(S.t1_ptr); dn.t1_step = up(st); dn.t1_ent = up(en);
-      dn.n11 = S.n11; dn.ell_npass = S.ell_npass; dn.ell_ti = S.ell_ti; dn.naux = S.n11 + S.ell_npass * S.ell_ti * 64 + 8;
-    }
     dn.nzl_stream = S.nzl_stream; dn.nzu_stream = S.nzu_stream;
     dn.Lrc = up(pack(S.Lrow, S.Lcol, S.Llev, (size_t)S.nzl_stream, dn.nchunkL));
     dn.Urc = up(pack(S.Urow, S.Ucol, S.Ulev, (size_t)S.nzu_stream, dn.nchunkU));
@@ -552,8 +541,6 @@ void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   ws.ygood = alloc((size_t)slots * dn.npad);
   ws.acor = alloc((size_t)slots * dn.npad);
   ws.ewt = alloc((size_t)slots * dn.npad);
-  ws.Laux = alloc((size_t)slots * dn.naux + 64);
-  HIP_OK(hipMemset(ws.Laux, 0, ((size_t)slots * dn.naux + 64) * sizeof(double))); // the empty ELL slots stay 0
   void *c = nullptr;
   HIP_OK(hipMalloc(&c, 64));
   ws_allocs.push_back(c);

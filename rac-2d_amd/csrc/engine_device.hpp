@@ -377,11 +377,8 @@ RG_DEV void lds_sync() {
 #define RG_CLAMP_LOADS 1
 #endif
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
-                   double *__restrict__ Dinv, double *__restrict__ Laux, double *__restrict__ sav, double *w, double *dl, double *w2, int lane,
-                   long long *cyc = nullptr, double *dmy = nullptr) {
-  // dmy: 64 spare LDS doubles, one per lane (RG_BRANCHFREE and the trailing-column phases)
-  // Laux: the wave's copy of the sparse columns' L entries for the trailing-column phases (device_tables.hpp, aux_of_L)
-  // w2 / sav: the third LDS vector (holds f(y) in the integrator) and where its content is kept meanwhile (HBM, n doubles)
+                   double *__restrict__ Dinv, double *w, double *dl, int lane, long long *cyc = nullptr, double *dmy = nullptr) {
+  // dmy: 64 spare LDS doubles, one per lane (RG_BRANCHFREE)
   // w: LDS work column;
   // dl: LDS copy of D^-1 (the U columns are scaled by it, and a gather from LDS beats one from HBM)
   bool ok = true;
@@ -389,7 +386,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 #define RG_TICK(acc) if (cyc) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - tq; tq = now_; }
   const int n = N.nS, ns = N.ns;
   const rsrc_t bLrow = mkbuf(N.Lrow), bUrow = mkbuf(N.Urow), bProw = mkbuf(N.Prow), bUdesc = mkbuf(N.Udesc), bP = mkbuf(Pv), bL = mkbuf(Lv),
-               bU = mkbuf(Uv), bX = mkbuf(Laux), bAux = mkbuf(N.aux_of_L);
+               bU = mkbuf(Uv);
   const int l2 = lane * 2, l8 = lane * 8; // lane part of every byte offset (u16 and 8-byte arrays)
   const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column
   auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; r.j = c[9]; return r; };
@@ -512,12 +509,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
     if (lane == 0) { Dinv[j] = dinv; dl[j] = dinv; wv[j] = 0.0; }
-    if (hasL) { const double lval = lv * dinv; sstore_f64(bL, l8, cur.lc0 * 8, lval); sstore_f64(bX, (int)bload_u16(bAux, l2, cur.lc0 * 2) * 8, 0, lval); wv[il] = 0.0; }
-    for (int q = cur.lc0 + 64 + lane; q < cur.lc1; q += 64) {
-      const int i = bload_u16(bLrow, q * 2, 0);
-      const double lval = wv[i] * dinv;
-      sstore_f64(bL, q * 8, 0, lval); sstore_f64(bX, (int)bload_u16(bAux, q * 2, 0) * 8, 0, lval); wv[i] = 0.0;
-    }
+    if (hasL) { sstore_f64(bL, l8, cur.lc0 * 8, lv * dinv); wv[il] = 0.0; }
+    for (int q = cur.lc0 + 64 + lane; q < cur.lc1; q += 64) { const int i = bload_u16(bLrow, q * 2, 0); sstore_f64(bL, q * 8, 0, wv[i] * dinv); wv[i] = 0.0; }
     wave_sync(); // L, U, Dinv of this column are read back from HBM by later columns
     RG_TICK(c_fin)
   };
@@ -547,11 +540,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     lds_sync();
     for (int q0 = 0; q0 < N.nleaf_ent; q0 += 64) {
       const unsigned long long e = bload_u64(bLe, l8, q0 * 8);
-      if (q0 + lane < N.nleaf_ent) {
-        const int lp = (int)((e >> 20) & 0xfffff);
-        const double lval = sload_f64(bP, (int)(e & 0xfffff) * 8, 0) * dl[(int)(e >> 40)];
-        sstore_f64(bL, lp * 8, 0, lval); sstore_f64(bX, (int)bload_u16(bAux, lp * 2, 0) * 8, 0, lval);
-      }
+      if (q0 + lane < N.nleaf_ent)
+        sstore_f64(bL, (int)((e >> 20) & 0xfffff) * 8, 0, sload_f64(bP, (int)(e & 0xfffff) * 8, 0) * dl[(int)(e >> 40)]);
     }
     wave_sync();
     RG_TICK(c_fin)
@@ -569,97 +559,22 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 #define RG_DENSE_G 12
 #endif
   constexpr int G = RG_DENSE_G;
-  static_assert(G % 3 == 0, "the trailing columns enter the dense phase three at a time");
-  // ---- the part of the trailing columns with rows and pivots < ns: two vectorised phases, three columns at a time ------------
-  // (network.hpp, struct Symbolic.)  The three columns use the three LDS vectors as work columns: w, the D^-1 copy (its values
-  // for k < ns are read from HBM from here on) and the vector that holds f(y), whose content waits in `sav`.
-  double *const w0 = w, *const w1 = dl;
-  {
-    const rsrc_t bS = mkbuf(sav);
-    for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) { sstore_f64(bS, l8, i0 * 8, w2[i]); w2[i] = 0.0; w1[i] = 0.0; } }
-    lds_sync();
-  }
-  const rsrc_t bDi = mkbuf(Dinv), bStep = mkbuf(N.t1_step), bEnt = mkbuf(N.t1_ent), bEk = mkbuf(N.ell_k), bEr = mkbuf(N.ell_row);
-  const RG_GLOBAL int *t1p = gptr(N.t1_ptr);
-  const int l4 = lane * 4, n11 = N.n11, TI = N.ell_ti;
-  auto phase1_step = [&](double *wg, int s_) { // one dependency level of one column: w[row] -= L11(row, k) * w[k]
-    const uint32_t sd = bload_u32(bStep, 0, s_ * 4);
-    const int first = (int)(sd & 0xffffffu), cnt = (int)(sd >> 24);
-    const uint32_t e = bload_u32(bEnt, min(l4, (cnt - 1) * 4), first * 4);
-    const double lval = sload_f64(bX, (int)(e >> 20) * 8, 0);
-    const double m = wg[e & 1023u];
-    atomicAdd(lane < cnt ? &wg[(e >> 10) & 1023u] : &dmy[lane], -(lval * m));
-  };
-  auto trail3 = [&](int jb, double &a0, double &b0, double &a1, double &b1, double &a2, double &b2) {
-    double *const wg[3] = {w0, w1, w2};
-    const int t = jb - ns, ncol = min(3, n - jb);
-    LuCol cc[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) cc[g] = load_col(N.nwork_sparse + min(t + g, nt - 1));
-    // 1. the columns of P into their work columns
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-      if (g < ncol)
-        for (int q = cc[g].p0 + lane; q < cc[g].p1; q += 64) wg[g][bload_u16(bProw, q * 2, 0)] = sload_f64(bP, q * 8, 0);
-    lds_sync();
-    RG_TICK(c_scatter)
-    // 2. phase 1, the levels of the three columns interleaved (they do not depend on each other)
-    {
-      int s_[3], e_[3], m = 0;
-#pragma unroll
-      for (int g = 0; g < 3; ++g) { s_[g] = t1p[min(t + g, nt)]; e_[g] = g < ncol ? t1p[min(t + g + 1, nt)] : s_[g]; m = max(m, e_[g] - s_[g]); }
-      for (int i = 0; i < m; ++i) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) if (s_[g] + i < e_[g]) phase1_step(wg[g], s_[g] + i);
-        lds_order();
-      }
-    }
-    lds_sync();
-    // 3. phase 2: tail rows -= L21 * u for the three columns at once, every lane one virtual row per pass
-    for (int pass = 0; pass < N.ell_npass; ++pass) {
-      double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-      const int base = pass * TI * 64;
-      for (int it = 0; it < TI; ++it) {
-        const double lval = sload_f64(bX, l8, (n11 + base + it * 64) * 8);
-        const int k = bload_u16(bEk, l2, (base + it * 64) * 2);
-        c0 += lval * w0[k]; c1 += lval * w1[k]; c2 += lval * w2[k];
-      }
-      const int row = bload_u16(bEr, l2, pass * 128);
-      const bool has = row != 0xffff;
-      atomicAdd(has ? &w0[row] : &dmy[lane], -c0);
-      atomicAdd(has ? &w1[row] : &dmy[lane], -c1);
-      atomicAdd(has ? &w2[row] : &dmy[lane], -c2);
-    }
-    lds_sync();
-    RG_TICK(c_rect)
-    // 4. rows < ns are final: scaled into U; the tail rows move to registers; the work columns go back to zero
-    double ta[3], tb[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      ta[g] = 0.0; tb[g] = 0.0;
-      if (g < ncol) {
-        for (int q = cc[g].u0 + lane; q < cc[g].ur; q += 64) {
-          const int k = bload_u16(bUrow, q * 2, 0);
-          sstore_f64(bU, q * 8, 0, wg[g][k] * bload_f64(bDi, k * 8, 0));
-          wg[g][k] = 0.0;
-        }
-        if (rowA < n) { ta[g] = wg[g][rowA]; wg[g][rowA] = 0.0; }
-        if (rowB < n) { tb[g] = wg[g][rowB]; wg[g][rowB] = 0.0; }
-      }
-    }
-    lds_sync();
-    a0 = ta[0]; b0 = tb[0]; a1 = ta[1]; b1 = tb[1]; a2 = ta[2]; b2 = tb[2];
-    RG_TICK(c_fin)
-  };
-  double dA = 0.0, dB = 0.0; // D^-1 of the tail rows this lane owns, once their columns are done
   for (; j < n; j += G) {
     const int ng = min(G, n - j);
     double wA[G], wB[G];
 #pragma unroll
-    for (int c = 0; c < G; ++c) { wA[c] = 0.0; wB[c] = 0.0; }
-#pragma unroll
-    for (int c = 0; c < G; c += 3)
-      if (c < ng) trail3(j + c, wA[c], wB[c], wA[c + 1], wB[c + 1], wA[c + 2], wB[c + 2]);
+    for (int c = 0; c < G; ++c) {
+      wA[c] = 0.0; wB[c] = 0.0;
+      if (c < ng) {
+        const int jc = j + c;
+        rect_phase(N.nwork_sparse + (jc - ns), w);
+        store_u(w, cur.ur);
+        if (rowA < n) { wA[c] = w[rowA]; w[rowA] = 0.0; }
+        if (rowB < n) { wB[c] = w[rowB]; w[rowB] = 0.0; }
+        lds_sync();
+        RG_TICK(c_fin)
+      }
+    }
 #define RG_DENSE_LOAD(LA, LB, kb_)                                                                               \
   _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
     const int k = min((kb_) + u, max(j - 1, ns)), kk = k - ns;                                                    \
@@ -699,9 +614,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
         const double d = bcast(wA[c], wB[c], kk);
         if (d == 0.0) ok = false;
         const double dinv = 1.0 / d;
-        if (lane == 0) Dinv[jc] = dinv;
-        if (rowA == jc) dA = dinv;
-        if (rowB == jc) dB = dinv;
+        if (lane == 0) { Dinv[jc] = dinv; dl[jc] = dinv; }
         const double lA = (rowA > jc && rowA < n) ? wA[c] * dinv : 0.0, lB = (rowB > jc && rowB < n) ? wB[c] * dinv : 0.0;
 #pragma unroll
         for (int c2 = c + 1; c2 < G; ++c2) {
@@ -710,21 +623,17 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
             wA[c2] -= lA * t; wB[c2] -= lB * t;
           }
         }
+        lds_sync(); // dl[jc] is read below by the lanes of later columns
         const int ub = ((nzus + kk * (kk - 1) / 2) - ns) * 8;                    // byte offset of U(0, jc): rows ns <= row < jc are stored
         const int lb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - jc - 1) * 8; // byte offset of L(0, jc): rows > jc are stored
-        if (rowA < jc) sstore_f64(bU, rA8, ub, wA[c] * dA);
+        if (rowA < jc) sstore_f64(bU, rA8, ub, wA[c] * dl[rowA]);
         else if (rowA > jc && rowA < n) sstore_f64(bL, rA8, lb, lA);
-        if (rowB < jc) sstore_f64(bU, rB8, ub, wB[c] * dB);
+        if (rowB < jc) sstore_f64(bU, rB8, ub, wB[c] * dl[rowB]);
         else if (rowB > jc && rowB < n) sstore_f64(bL, rB8, lb, lB);
       }
     }
     wave_sync(); // L, U, Dinv of these columns are read back from HBM by later columns
     RG_TICK(c_fin)
-  }
-  {
-    const rsrc_t bS = mkbuf(sav);
-    for (int i0 = 0; i0 < n; i0 += 64) { const double v = sload_f64(bS, l8, i0 * 8); if (i0 + lane < n) w2[i0 + lane] = v; }
-    lds_sync();
   }
   if (cyc) { cyc[0] += c_scatter; cyc[1] += c_rect; cyc[2] += c_dense; cyc[3] += c_fin; }
 #undef RG_TICK

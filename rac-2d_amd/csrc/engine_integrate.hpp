@@ -19,7 +19,7 @@ namespace racgpu {
 struct CellCtx {
   double *y, *savf, *wx;                                       // LDS, nS doubles each: iterate, f(y), linear-solver work vector
   double *acor, *ewt;                                          // HBM, npad each: accumulated correction, inverse error weights (elementwise use only)
-  double *yh, *Pv, *Lv, *Uv, *Dinv, *Laux, *rates, *rtol, *atol; // this cell's HBM slices
+  double *yh, *Pv, *Lv, *Uv, *Dinv, *rates, *rtol, *atol;      // this cell's HBM slices
   int lane, n, npad;
   int *marker;    // developer aid: host-visible progress word, or null
 };
@@ -158,8 +158,7 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   {
     const long long t0 = dev_clock();
     long long part[4] = {0, 0, 0, 0};
-    // (the third LDS vector holds f(y), needed after the factorisation: it waits in the acor slice, which the corrector zeroes next)
-    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.Laux, c.acor, c.wx, c.y, c.savf, c.lane, part, c.wx + ((c.n + 1) & ~1))) s.ierpj = 1;
+    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, part, c.wx + ((c.n + 1) & ~1))) s.ierpj = 1;
     cyc_add(CYC_LU, dev_clock() - t0);
     for (int k = 0; k < 4; ++k) cyc_add(CYC_LU_PART + k, part[k]);
   }

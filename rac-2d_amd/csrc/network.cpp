@@ -228,7 +228,6 @@ void parse_network(const std::string &path, HostNetwork &net) {
   }
   build_jacobian_tables(net);
   build_symbolic(net);
-  build_trailing_tables(net);
   build_reference_layout(net);
 }
 
@@ -478,72 +477,6 @@ void build_symbolic(HostNetwork &net) {
   }
   S.Ppos.assign(S.Psrc.size(), 0);
   for (size_t q = 0; q < S.Psrc.size(); ++q) S.Ppos[S.Psrc[q]] = (int)q;
-}
-
-// Tables of the two-phase treatment of the trailing columns (network.hpp, struct Symbolic).
-void build_trailing_tables(HostNetwork &net) {
-  Symbolic &S = net.sym;
-  const int n = S.n, ns = S.ns, nt = n - ns;
-  if (n > 1023) throw std::runtime_error("more than 1023 species: 10-bit indices of the trailing-column tables exhausted");
-  // Laux slots: first the L11 entries in storage order, then the ELL slots
-  S.aux_of_L.assign((size_t)S.nzl_stream, -1);
-  std::vector<int> l11_of(S.nzl_stream, -1);
-  S.n11 = 0;
-  for (int k = 0; k < ns; ++k)
-    for (int p = S.Lcolptr[k]; p < S.Lcolend[k]; ++p)
-      if (S.Lrow[p] < ns) { l11_of[p] = S.n11; S.aux_of_L[p] = S.n11; S.n11++; }
-  if (S.n11 >= 4096) throw std::runtime_error("L11 has 4096 or more entries: 12-bit index of the phase-1 table exhausted");
-  // ---- phase 2: virtual rows of at most TI entries, 64 per pass, longest rows first
-  const int TI = 16;
-  struct VRow { int row; std::vector<int> pos; };
-  std::vector<std::vector<int>> byrow(n);
-  for (int k = 0; k < ns; ++k)
-    for (int p = S.Lcolptr[k]; p < S.Lcolend[k]; ++p) if (S.Lrow[p] >= ns) byrow[S.Lrow[p]].push_back(p);
-  std::vector<VRow> vr;
-  for (int r = ns; r < n; ++r)
-    for (size_t a = 0; a < byrow[r].size(); a += TI) {
-      VRow v; v.row = r;
-      for (size_t b = a; b < std::min(byrow[r].size(), a + TI); ++b) v.pos.push_back(byrow[r][b]);
-      vr.push_back(v);
-    }
-  S.ell_ti = TI;
-  S.ell_npass = (int)((vr.size() + 63) / 64);
-  S.ell_k.assign((size_t)S.ell_npass * TI * 64, 0);
-  S.ell_row.assign((size_t)S.ell_npass * 64, 0xffff);
-  for (size_t v = 0; v < vr.size(); ++v) {
-    const int pass = (int)(v / 64), lane = (int)(v % 64);
-    S.ell_row[(size_t)pass * 64 + lane] = (uint16_t)vr[v].row;
-    for (size_t it = 0; it < vr[v].pos.size(); ++it) {
-      const size_t slot = ((size_t)pass * TI + it) * 64 + lane;
-      const int p = vr[v].pos[it];
-      S.aux_of_L[p] = S.n11 + (int)slot;
-      S.ell_k[slot] = (uint16_t)S.Lcol[p];
-    }
-  }
-  if (S.n11 + S.ell_npass * TI * 64 > 65535) throw std::runtime_error("Laux exceeds 16-bit slot numbers");
-  // ---- phase 1: per trailing column, per level of its pivots, the L11 entries of those pivots
-  S.t1_ptr.assign(nt + 1, 0);
-  S.t1_step.clear(); S.t1_ent.clear();
-  for (int j = ns; j < n; ++j) {
-    std::vector<uint32_t> cur;
-    auto flush = [&]() {
-      for (size_t a = 0; a < cur.size(); a += 64) {
-        const size_t c = std::min<size_t>(64, cur.size() - a);
-        S.t1_step.push_back((uint32_t)S.t1_ent.size() | ((uint32_t)c << 24));
-        S.t1_ent.insert(S.t1_ent.end(), cur.begin() + a, cur.begin() + a + c);
-      }
-      cur.clear();
-    };
-    for (int q = S.Ucolptr[j]; q < S.Ucolend[j]; ++q) {
-      if (S.Ugrp[q]) flush(); // a new level of this column's pivots
-      const int k = S.Urow[q];
-      for (int p = S.Lcolptr[k]; p < S.Lcolend[k]; ++p)
-        if (S.Lrow[p] < ns) cur.push_back((uint32_t)k | ((uint32_t)S.Lrow[p] << 10) | ((uint32_t)l11_of[p] << 20));
-    }
-    flush();
-    S.t1_ptr[j - ns + 1] = (int)S.t1_step.size();
-  }
-  if (S.t1_ent.size() >= (1u << 24)) throw std::runtime_error("phase-1 table exceeds 2^24 entries");
 }
 
 // The reference's pattern and the storage order of its P (see HostNetwork::ref_kref).

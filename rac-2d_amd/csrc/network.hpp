@@ -58,21 +58,6 @@ struct Symbolic { // LU structure of P = I - gamma*J on the species block, cell 
   std::vector<int> Pcolptr, Psrc, Prow, Ppos;
   int nzl = 0, nzu = 0;                 // storage sizes of L and U (with the level-alignment padding of the streamed parts)
   int nzl_entries = 0, nzu_entries = 0; // entries of the factors proper
-  // ---- trailing columns j >= ns: their part with rows/pivots < ns, in two vectorised phases (build_trailing_tables) ----
-  // Phase 1, per column: u_j = L11^-1 a_j restricted to the column's pattern, one step per dependency level; a step holds the
-  //   L11 entries (k, row, value) of all pivots of that level (<= 64 per step): w[row] -= l * w[k].
-  // Phase 2, three columns at a time: tail(j) -= L21 * u_j as a product over ALL entries of L21 held in a lane-major copy
-  //   ("ELL": every lane owns one virtual row of <= ell_ti entries per pass); entries whose pivot is outside a column's
-  //   pattern multiply an exact zero.
-  // Both read a per-wave copy `Laux` of the L entries of the sparse columns: [0, n11) the L11 entries, then the ELL slots.
-  int n11 = 0;                          // entries of L11 (rows and columns < ns)
-  int ell_npass = 0, ell_ti = 0;        // ELL geometry: npass passes of ti iterations of 64 lanes
-  std::vector<int> aux_of_L;            // [nzl_stream]: slot in Laux of the L entry stored at that position of the stream (-1: padding)
-  std::vector<uint16_t> ell_k;          // [npass*ti*64]: pivot column of the entry in that slot (0 for an empty slot: its value stays 0)
-  std::vector<uint16_t> ell_row;        // [npass*64]: row the lane's virtual row of that pass adds into (0xffff: none)
-  std::vector<int> t1_ptr;              // [n - ns + 1]: steps of trailing column ns + t
-  std::vector<uint32_t> t1_step;        // per step: first entry | count << 24
-  std::vector<uint32_t> t1_ent;         // per entry: k | row << 10 | index in [0, n11) << 20
 };
 
 struct HostNetwork {
@@ -111,7 +96,6 @@ void load_initial_abundances(const HostNetwork &net, const std::string &path, do
 void build_jacobian_tables(HostNetwork &net);
 void build_symbolic(HostNetwork &net);
 void build_reference_layout(HostNetwork &net);
-void build_trailing_tables(HostNetwork &net);
 double fortran_real_field(const char *s, int w);
 
 } // namespace racgpu

@@ -18,7 +18,7 @@ print("n=%d wall %.1fs kernel %.0f ms  total steps %d  -> %.0f steps/s (kernel)"
 print("NST percentiles 50/90/99/max:", np.percentile(st[:, 0], [50, 90, 99, 100]))
 print("cycles/cell percentiles 50/90/99/max (1e9):", np.percentile(st[:, 8], [50, 90, 99, 100]) / 1e9, " sum/2048 %.2fe9" % (st[:, 8].sum() / 2048 / 1e9))
 print("quality!=0:", (out["quality"] != 0).sum(), " NERR>0:", (st[:, 4] > 0).sum(), " tfinal<tmax:", (out["t_final"] < cells[:, 27]).sum())
-print("cycles per step %.3fM; phase shares rhs %.3f jac %.3f lu %.3f solve %.3f" % (st[:, 8].sum() / st[:, 0].sum() / 1e6, *[st[:, k].sum() / st[:, 8].sum() for k in (9, 10, 11, 12)]))
+print("cycles per step %.3fM; phase shares rhs %.3f jac %.3f lu %.3f solve %.3f | lu: scatter %.3f lds/phases %.3f dense %.3f" % (st[:, 8].sum() / st[:, 0].sum() / 1e6, *[st[:, k].sum() / st[:, 8].sum() for k in (9, 10, 11, 12, 13, 14, 15)]))
 worst = np.argsort(-st[:, 8])[:10]
 for w in worst:
     print("cell %5d: T=%.1f Td=%.1f n=%.2e AvS=%.3g G0=%.2e tmax=%.2e NST=%d NFE=%d NJE=%d NLU=%d NERR=%d nrec=%d q=%d tf=%.3g cyc=%.2fe9" % (
