@@ -130,6 +130,12 @@ int racgpu_species_index(const racgpu_network *, const char *name);             
 int racgpu_reactions(const racgpu_network *, int32_t *reac, int32_t *prod, int32_t *n_reac, int32_t *n_prod, int32_t *itype, int32_t *n_dupli);
 /* species attributes: mass_num, vib_freq, Edesorb [nS] (NaN where the reference leaves NaN), counterpart (-1 none), charge */
 int racgpu_species_attrs(const racgpu_network *, double *mass_num, double *vib_freq, double *Edesorb, int32_t *counterpart, int32_t *charge);
+/* chem_species%elements(1:20, i) (src/chemistry.f90:21-34: charge, E, Grain, H, D, He, C, N, O, Si, S, Fe, Na, Mg, Cl, P, F, Ne, Ar, K): elements[nS*20] */
+int racgpu_species_elements(const racgpu_network *, int32_t *elements);
+/* the reaction rows as read (chem_load_reactions, src/chemistry.f90:1364-1424): ABC[nR*3], T_range[nR*2], ctype[nR*2] and
+ * reliability[nR] (characters, not terminated), names[nR*7*12] = reac_names(1:3), prod_names(1:4), blank padded; any may be NULL.
+ * What the per-cell rate dump (save_chem_rates, src/disk.f90:3555-3592) and chem_analyse (:4136-4300) print next to a rate. */
+int racgpu_reaction_rows(const racgpu_network *, double *ABC, double *T_range, char *ctype, char *reliability, char *names);
 /* CSC pattern of the species-block Jacobian: colptr[nS+1], rowidx[nnzJ], 1-based */
 int racgpu_jac_pattern(const racgpu_network *, int32_t *colptr, int32_t *rowidx);
 

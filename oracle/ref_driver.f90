@@ -12,6 +12,7 @@
 ! Output: plain-text vectors, one value per line, %ES25.17E3.
 program ref_driver
   use chemistry
+  use trivials, only: double2str
   implicit none
   external chem_ode_f, chem_ode_jac
   character(len=256) :: nml_file, chem_dir, network, initial, out_dir, cell_file
@@ -21,11 +22,14 @@ program ref_driver
   ! nlocal_iter > 1: the local-iteration loop of calc_this_cell (src/disk.f90:1651-1791) around chem_evol_solve;
   ! tol_j: j of chem_set_solver_flags_alt for a single pass; y_override: file of rows "cell species value" applied to
   ! the initial condition (to provoke the sanity exits of src/chemistry.f90:520-530)
-  integer :: nlocal_iter, tol_j
+  integer :: nlocal_iter, tol_j, dump_analysis
+  character(len=9) :: strtmp
+  double precision, allocatable :: flux(:)
+  integer :: ie, isp, fA
   character(len=256) :: y_override
   namelist /ref_run/ chem_dir, network, initial, out_dir, cell_file, ncell, &
     rtol, atol, dt_first_step, ratio_tstep, t_max, mxstep, steps_reset, h2_moeq, &
-    dump_jac, dump_record_every, solve, nlocal_iter, tol_j, y_override, special_gH_mobi
+    dump_jac, dump_record_every, solve, nlocal_iter, tol_j, y_override, special_gH_mobi, dump_analysis
   double precision, allocatable :: abund(:)
   double precision :: t_final, t_end, dt0, tmp, ov_val
   integer :: jj, isav, qual_cell, ov_cell, ov_spe, fO, ios
@@ -41,7 +45,7 @@ program ref_driver
   ncell = 1; rtol = 1D-4; atol = 1D-30; dt_first_step = 1D-8; ratio_tstep = 1.1D0
   t_max = 1D6; mxstep = 6000; steps_reset = 50; h2_moeq = .false.
   dump_jac = 1; dump_record_every = 0; solve = 1
-  nlocal_iter = 1; tol_j = 1; y_override = ''; special_gH_mobi = .false.
+  nlocal_iter = 1; tol_j = 1; y_override = ''; special_gH_mobi = .false.; dump_analysis = 0
   open(newunit=fU, file=trim(nml_file), status='old', action='read')
   read(fU, nml=ref_run)
   close(fU)
@@ -309,6 +313,50 @@ program ref_driver
             write(fC, '(ES25.17E3)') chemsol_stor%record(i, k)
           end do
         end do
+      end if
+      if (dump_analysis .ne. 0) then
+        ! the reference's own analysis of the end state: chem_ode_f_alt, get_contribution_each, chem_elemental_residence
+        ! (src/chemistry.f90:1593-1854) and the rows of save_chem_rates (src/disk.f90:3573-3589)
+        allocate(flux(chem_net%nReactions))
+        call chem_ode_f_alt(chem_net%nReactions, flux, NEQ, chemsol_stor%y)
+        write(fC, '(A, I8)') '# flux ', chem_net%nReactions
+        do i = 1, chem_net%nReactions
+          write(fC, '(ES25.17E3)') flux(i)
+        end do
+        deallocate(flux)
+        call get_species_produ_destr
+        call get_contribution_each
+        do k = 1, 10
+          isp = chem_idx_some_spe%idx(k)
+          write(fC, '(A, I8, I8)') '# produ ', 2 * min(chem_species%produ(isp)%nItem, 20), isp
+          do j = 1, min(chem_species%produ(isp)%nItem, 20)
+            write(fC, '(ES25.17E3)') dble(chem_species%produ(isp)%list(j))
+            write(fC, '(ES25.17E3)') chem_species%produ(isp)%contri(j)
+          end do
+          write(fC, '(A, I8, I8)') '# destr ', 2 * min(chem_species%destr(isp)%nItem, 20), isp
+          do j = 1, min(chem_species%destr(isp)%nItem, 20)
+            write(fC, '(ES25.17E3)') dble(chem_species%destr(isp)%list(j))
+            write(fC, '(ES25.17E3)') chem_species%destr(isp)%contri(j)
+          end do
+        end do
+        call chem_elemental_residence
+        do ie = 1, const_nElement
+          write(fC, '(A, I8, I8)') '# eleres ', 3 * chem_ele_resi(ie)%n_nonzero, ie
+          do j = 1, chem_ele_resi(ie)%n_nonzero
+            write(fC, '(ES25.17E3)') dble(chem_ele_resi(ie)%iSpecies(j))
+            write(fC, '(ES25.17E3)') chem_ele_resi(ie)%ele_frac(j)
+            write(fC, '(ES25.17E3)') chem_ele_resi(ie)%ele_accu(j)
+          end do
+        end do
+        write(fname, '(A, "/ratedump_", I4.4, ".txt")') trim(out_dir), ic
+        open(newunit=fA, file=trim(fname), status='replace')
+        do k = 1, chem_net%nReactions
+          call double2str(strtmp, chem_net%ABC(3, k), 9, 1)
+          write(fA, '(7(A12), ES9.2, F9.2, A9, 2I6, I3, X, A1, X, A2, ES16.6E3)') &
+            chem_net%reac_names(:,k), chem_net%prod_names(:,k), chem_net%ABC(1:2,k), strtmp, &
+            int(chem_net%T_range(:,k)), chem_net%itype(k), chem_net%reliability(k), chem_net%ctype(k), chem_net%rates(k)
+        end do
+        close(fA)
       end if
       ! RHS at the end state: second ydot pin, at a chemically evolved composition.
       call chem_ode_f(NEQ, tdummy, chemsol_stor%y, ydot)

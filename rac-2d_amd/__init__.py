@@ -16,6 +16,7 @@ import os
 import numpy as np
 
 from . import cells  # noqa: F401  (synthetic cell records)
+from . import analysis  # noqa: F401  (rate dump, contributions, elemental reservoirs)
 from .cells import NPAR
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -32,7 +33,7 @@ O_R_H2_FORM, O_N_MOL_ON_GRAIN, O_T_END = range(NOUT)
 ABI_SYMBOLS = [
     "racgpu_last_error", "racgpu_device_count", "racgpu_network_load", "racgpu_network_destroy",
     "racgpu_network_dims", "racgpu_network_set_reference_lenrw", "racgpu_network_reference_lenrw", "racgpu_species_name", "racgpu_species_index", "racgpu_reactions",
-    "racgpu_species_attrs", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
+    "racgpu_species_attrs", "racgpu_species_elements", "racgpu_reaction_rows", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
     "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_rectify_abundances",
@@ -88,6 +89,8 @@ def lib():
     L.racgpu_reactions.argtypes = [vp, ip, ip, ip, ip, ip, ip]
     L.racgpu_species_attrs.argtypes = [vp, dp, dp, dp, ip, ip]
     L.racgpu_jac_pattern.argtypes = [vp, ip, ip]
+    L.racgpu_species_elements.argtypes = [vp, ip]
+    L.racgpu_reaction_rows.argtypes = [vp, dp, dp, C.c_char_p, C.c_char_p, C.c_char_p]
     L.racgpu_load_initial_abundances.argtypes = [vp, C.c_char_p, dp]
     L.racgpu_params_default.argtypes = [pp]
     L.racgpu_n_record.argtypes = [pp, C.c_double, C.c_double]
@@ -195,6 +198,22 @@ class Network:
         m = np.zeros(nS); v = np.zeros(nS); e = np.zeros(nS); cp = np.zeros(nS, np.int32); ch = np.zeros(nS, np.int32)
         _check(lib().racgpu_species_attrs(self._h, _dp(m), _dp(v), _dp(e), _ip(cp), _ip(ch)))
         return dict(mass_num=m, vib_freq=v, Edesorb=e, counterpart=cp, charge=ch)
+
+    def species_elements(self):
+        """chem_species%elements: [nS, 20] (column 0 = charge)."""
+        el = np.zeros((self.nSpecies, 20), np.int32)
+        _check(lib().racgpu_species_elements(self._h, _ip(el)))
+        return el
+
+    def reaction_rows(self):
+        """ABC, T_range, ctype, reliability and the seven name fields of every reaction row as read from the network file."""
+        nR = self.nReactions
+        abc = np.zeros((nR, 3)); tr = np.zeros((nR, 2))
+        ct = C.create_string_buffer(2 * nR); rl = C.create_string_buffer(nR); nm = C.create_string_buffer(nR * 84)
+        _check(lib().racgpu_reaction_rows(self._h, _dp(abc), _dp(tr), ct, rl, nm))
+        names = [[nm.raw[(r * 7 + k) * 12:(r * 7 + k + 1) * 12].decode() for k in range(7)] for r in range(nR)]
+        return dict(ABC=abc, T_range=tr, ctype=[ct.raw[2 * r:2 * r + 2].decode() for r in range(nR)],
+                    reliability=[rl.raw[r:r + 1].decode() for r in range(nR)], names=names)
 
     def jac_pattern(self):
         colptr = np.zeros(self.nSpecies + 1, np.int32); rowidx = np.zeros(self.nnzJ, np.int32)

@@ -681,6 +681,30 @@ int racgpu_species_attrs(const racgpu_network *h, double *mass, double *vib, dou
   return 0;
 }
 
+int racgpu_species_elements(const racgpu_network *h, int32_t *el) {
+  if (!h || !el) return fail("null argument");
+  for (int i = 0; i < h->net.nS; ++i) for (int e = 0; e < kNumElements; ++e) el[i * kNumElements + e] = h->net.elements[i][e];
+  return 0;
+}
+
+int racgpu_reaction_rows(const racgpu_network *h, double *ABC, double *Tr, char *ctype, char *rel, char *names) {
+  if (!h) return fail("null network");
+  for (int r = 0; r < h->net.nR; ++r) {
+    const Reaction &x = h->net.R[r];
+    if (ABC) for (int k = 0; k < 3; ++k) ABC[3 * r + k] = x.ABC[k];
+    if (Tr) for (int k = 0; k < 2; ++k) Tr[2 * r + k] = x.Trange[k];
+    if (ctype) { ctype[2 * r] = x.ctype[0]; ctype[2 * r + 1] = x.ctype[1]; }
+    if (rel) rel[r] = x.reliability;
+    if (names)
+      for (int k = 0; k < 7; ++k) {
+        const std::string &nm = k < 3 ? x.rname[k] : x.pname[k - 3];
+        char *dst = names + ((size_t)r * 7 + k) * 12;
+        for (int c = 0; c < 12; ++c) dst[c] = c < (int)nm.size() ? nm[c] : ' ';
+      }
+  }
+  return 0;
+}
+
 int racgpu_jac_pattern(const racgpu_network *h, int32_t *colptr, int32_t *rowidx) {
   if (!h) return fail("null network");
   if (colptr) for (int j = 0; j <= h->net.nS; ++j) colptr[j] = h->net.Jcolptr[j] + 1;

@@ -129,6 +129,7 @@ void parse_network(const std::string &path, HostNetwork &net) {
       x.itype = it.empty() ? 0 : std::atoi(it.c_str());
     }
     x.ctype[0] = row[129]; x.ctype[1] = row[130]; x.ctype[2] = 0;
+    x.reliability = row[127];
     for (int k = 0; k < 3; ++k) {
       if (!x.rname[k].empty()) x.n_reac++;
       if (x.rname[k] == "PHOTON" || x.rname[k] == "CRPHOT" || x.rname[k] == "CRP") x.n_reac--;

@@ -25,6 +25,7 @@ struct Reaction {
   double ABC[3] = {0, 0, 0}, Trange[2] = {0, 0};
   int itype = 0;
   char ctype[3] = {' ', ' ', 0};
+  char reliability = ' ';
   int n_reac = 0, n_prod = 0;
   int reac[3] = {0, 0, 0}, prod[4] = {0, 0, 0, 0}; // 1-based species indices
 };

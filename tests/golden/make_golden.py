@@ -60,7 +60,7 @@ def read_cell(fn):
 
 
 def run_ref(network, initial, cells, rtol, t_max, steps_reset, dump_jac, solve=1, atol=1e-30, mxstep=6000, nlocal_iter=1, tol_j=1,
-            y_override=None, special_gH_mobi=False):
+            y_override=None, special_gH_mobi=False, dump_analysis=0):
     """y_override: list of (cell (1-based), species (1-based), value) applied to the initial condition."""
     with tempfile.TemporaryDirectory() as td:
         np.savetxt(os.path.join(td, "cells.txt"), cells, fmt="%.17e")
@@ -73,14 +73,17 @@ def run_ref(network, initial, cells, rtol, t_max, steps_reset, dump_jac, solve=1
         with open(os.path.join(td, "run.nml"), "w") as f:
             f.write("&ref_run\n chem_dir='%s'\n network='%s'\n initial='%s'\n out_dir='%s'\n cell_file='%s'\n"
                     " ncell=%d\n rtol=%.17e\n atol=%.17e\n dt_first_step=1D-8\n ratio_tstep=1.1D0\n t_max=%.17e\n"
-                    " mxstep=%d\n steps_reset=%d\n dump_jac=%d\n solve=%d\n nlocal_iter=%d\n tol_j=%d\n special_gH_mobi=%s\n%s/\n"
+                    " mxstep=%d\n steps_reset=%d\n dump_jac=%d\n solve=%d\n nlocal_iter=%d\n tol_j=%d\n special_gH_mobi=%s\n dump_analysis=%d\n%s/\n"
                     % (INP, network, initial, td, os.path.join(td, "cells.txt"), len(cells), rtol, atol, t_max,
-                       mxstep, steps_reset, dump_jac, solve, nlocal_iter, tol_j, ".true." if special_gH_mobi else ".false.", ov))
+                       mxstep, steps_reset, dump_jac, solve, nlocal_iter, tol_j, ".true." if special_gH_mobi else ".false.", dump_analysis, ov))
         subprocess.run([DRIVER, os.path.join(td, "run.nml")], stdout=subprocess.DEVNULL, check=True)
         out = [read_cell(os.path.join(td, "cell_%04d.txt" % (i + 1))) for i in range(len(cells))]
         log = open(os.path.join(td, "ref_log.txt")).read()
-        for o in out:
+        for i, o in enumerate(out):
             o["_log"] = log
+            fn = os.path.join(td, "ratedump_%04d.txt" % (i + 1))
+            if os.path.exists(fn):
+                o["_ratedump"] = open(fn).read()
         meta = dict(
             species=[l.rstrip("\n") for l in open(os.path.join(td, "species.txt"))],
             network=np.loadtxt(os.path.join(td, "network.txt"), skiprows=1, dtype=np.int32),
@@ -200,6 +203,17 @@ def main_policy():
     r, _ = run_ref(network, initial, pc[:1], 1e-4, 1e6, 50, 0, y_override=[(1, iH, 2.5)], nlocal_iter=4)
     tab, ys = iters_of(r[0], nS)
     out["bigH_iters"] = tab; out["bigH_y"] = ys; out["bigH_species"] = iH
+
+    # (6) the reference's analysis of an end state: chem_ode_f_alt fluxes, production/destruction ranking of the ten special
+    # species, elemental reservoirs, and the rows of the per-cell rate dump
+    r, _ = run_ref(network, initial, pc[:1], 1e-4, 1e6, 50, 0, dump_analysis=1)
+    a = r[0]
+    out["ana_yend"] = a["yend"]; out["ana_rates"] = a["rates"]; out["ana_flux"] = a["flux"]
+    out["ana_produ_species"] = np.array(sorted(int(k.split("_")[1]) for k in a if k.startswith("produ_")))
+    for k in a:
+        if k.startswith(("produ_", "destr_", "eleres_")):
+            out["ana_" + k] = a[k]
+    out["ana_ratedump"] = np.array(a["_ratedump"])
 
     fn = os.path.join(HERE, "policy_grain.npz")
     np.savez_compressed(fn, **out)

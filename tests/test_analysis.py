@@ -1,0 +1,78 @@
+"""Analysis outputs against the reference's own: chem_ode_f_alt fluxes, production / destruction ranking,
+elemental reservoirs, and the rows of the per-cell rate dump -- captured from the unmodified reference at the end state of a
+configs[2] grid cell (tests/golden/policy_grain.npz, keys ana_*).  Host side only: no GPU needed (the rate coefficients and the
+end state are the reference's; on the GPU box the same functions take Network.cal_rates and the solver's output)."""
+import io
+
+import numpy as np
+
+from conftest import DATA, GOLDEN
+
+G = np.load(f"{GOLDEN}/policy_grain.npz")
+
+
+def _net(racgpu):
+    return racgpu.Network(f"{DATA}/{G['network_file']}")
+
+
+def test_reaction_fluxes_match_chem_ode_f_alt(racgpu):
+    net = _net(racgpu)
+    y = G["ana_yend"][:net.nSpecies]
+    flux = racgpu.analysis.reaction_fluxes(net, G["ana_rates"], y, G["policy_cells"][0])
+    ref = G["ana_flux"]
+    assert ((flux == 0) == (ref == 0)).all()
+    it = net.reactions()["itype"]
+    surf = np.isin(it, (62, 75))  # k (1 - exp(-t)) with t down to 1e-9: one ulp of exp is 1e-7 of the result
+    for m, tol in ((~surf, 1e-14), (surf, 1e-6)):
+        nz = (ref != 0) & m
+        assert np.max(np.abs(flux[nz] - ref[nz]) / np.abs(ref[nz])) <= tol
+
+
+def test_contribution_ranking_matches_get_contribution_each(racgpu):
+    net = _net(racgpu)
+    y = G["ana_yend"][:net.nSpecies]
+    species = [int(s) for s in G["ana_produ_species"]]
+    con = racgpu.analysis.contributions(net, G["ana_rates"], y, G["policy_cells"][0], species)
+    for sp in species:
+        for which, lst in zip(("produ", "destr"), con[sp]):
+            ref = G[f"ana_{which}_{sp}"].reshape(-1, 2)  # (reaction, contribution), the reference's top 20
+            got = lst[:len(ref)]
+            np.testing.assert_allclose([c for _, c in got], ref[:, 1], rtol=1e-6, atol=0)
+            # same reactions wherever the contributions differ (ties may be ordered differently by the two sorts)
+            for (i0, c), (r0, rc) in zip(got, ref):
+                if i0 != int(r0):
+                    assert abs(c - dict(lst)[int(r0)]) <= 1e-6 * abs(c), (sp, which, i0, int(r0))
+
+
+def test_elemental_residence_matches_reference(racgpu):
+    net = _net(racgpu)
+    y = G["ana_yend"][:net.nSpecies]
+    res = racgpu.analysis.elemental_residence(net, y)
+    for e in range(20):
+        ref = G[f"ana_eleres_{e + 1}"].reshape(-1, 3)
+        got = res[e]
+        assert len(got) == len(ref), (e, got, ref)
+        for (i0, frac, accu), (r0, rf, ra) in zip(got, ref):
+            if abs(rf) > 0:
+                assert i0 == int(r0)
+            np.testing.assert_allclose([frac, accu], [rf, ra], rtol=1e-13, atol=1e-300)
+
+
+def test_rate_dump_rows_are_the_references(racgpu, tmp_path):
+    net = _net(racgpu)
+    racgpu.analysis.write_rate_dump(tmp_path / "reac_rates_cell_0001.dat", net, G["ana_rates"])
+    got = open(tmp_path / "reac_rates_cell_0001.dat").read().splitlines()
+    ref = str(G["ana_ratedump"]).splitlines()
+    assert len(got) == len(ref) == net.nReactions
+    bad = [(k, g, r) for k, (g, r) in enumerate(zip(got, ref)) if g != r]
+    assert not bad, bad[:3]
+
+
+def test_snapshot_blocks_are_written(racgpu):
+    net = _net(racgpu)
+    y = G["ana_yend"][:net.nSpecies]
+    f = io.StringIO()
+    racgpu.analysis.write_elements(f, net, 1e6, y, 73.3)
+    racgpu.analysis.write_contributions(f, net, 1e6, y, G["ana_rates"], G["policy_cells"][0], [net.species_index("CO"), net.species_index("H2O")])
+    txt = f.getvalue()
+    assert "Total net charge" in txt and "Production" in txt and "Destruction" in txt and "CO  " in txt
