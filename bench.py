@@ -203,10 +203,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the racgpu path has no CPU fallback")
+    # RACGPU_BENCH_REHEARSAL=1 (developer aid): rehearse the N > 1 code path on a box with ONE GPU -- every rank computes on cuda:0
+    # and the exchange goes through gloo on host copies.  Never a measurement.
+    rehearsal = bool(os.environ.get("RACGPU_BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     R = importlib.import_module("rac-2d_amd")
     sweep = importlib.import_module("rac-2d_amd.sweep")
@@ -251,7 +259,7 @@ def main():
     stats_d = torch.zeros((ncell, R.NSTAT), dtype=torch.int64, device=dev)
     maxn = ncell
     if world > 1:
-        t = torch.tensor([ncell], dtype=torch.int64, device=dev)
+        t = torch.tensor([ncell], dtype=torch.int64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         maxn = int(t.item())
     block_d = torch.zeros((maxn, ncol), dtype=torch.float64, device=dev)
@@ -272,7 +280,12 @@ def main():
             block_d[:ncell, nS] = tfin_d
             block_d[:ncell, nS + 1] = qual_d.to(torch.float64)
             block_d[:ncell, nS + 2:] = stats_d.to(torch.float64)
-            dist.all_gather_into_tensor(gathered, block_d)  # the path's single exchange: RCCL over xGMI
+            if rehearsal:
+                gc = torch.empty(gathered.shape, dtype=torch.float64)
+                dist.all_gather_into_tensor(gc, block_d.cpu())
+                gathered.copy_(gc)
+            else:
+                dist.all_gather_into_tensor(gathered, block_d)  # the path's single exchange: RCCL over xGMI
         torch.cuda.synchronize(dev)
         kernel_ms.append(net.last_kernel_ms())
         if not args.no_hints:
@@ -302,7 +315,7 @@ def main():
 
     stats = stats_d.cpu().numpy()
     qual = qual_d.cpu().numpy()
-    local = torch.tensor([dt, float(stats[:, 0].sum()) * args.steps], dtype=torch.float64, device=dev)
+    local = torch.tensor([dt, float(stats[:, 0].sum()) * args.steps], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         tmax = local[0:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ssum = local[1:2].clone(); dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
@@ -332,7 +345,8 @@ def main():
         out = {
             "metric": "cell-steps/s (whole node)", "value": steps_all / t_all, "unit": "cell-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_all / args.steps,
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL of the multi-rank path on one GPU over gloo: not a measurement",
             "config": {"workload": wl, "cells_per_gpu": ncell,
                        "parallelism": "cells sharded over %d GPU(s) (%s), one RCCL all-gather of abundances + t_final + quality + counters at output" % (world, args.scaling),
                        "local_iterations": args.nlocal_iter,
