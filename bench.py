@@ -129,7 +129,7 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                     "sample": "%d cells of the same batch (every %d-th), reference Fortran/DLSODES binary, %d processes, %.1f s wall; "
                               "steps counted with the GPU run's NST for the same cells (DLSODES zeroes its own counter at every solver reset)"
                               % (nsample, max(1, len(cells) // nsample), min(cores, nsample), dt)}
-            errs, tf_eq, q_eq = [], 0, 0
+            errs, tf_eq, q_eq, ne_eq, ne_ref, ne_gpu = [], 0, 0, 0, 0, 0
             for k in range(nsample):
                 r = ref[k]
                 yr = r["yend"][:nS]
@@ -138,11 +138,14 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                 errs.append(float(np.max(np.abs(yg[m] - yr[m]) / yr[m])))
                 tf_eq += int(r["scalars"][0] == gpu["t_final"][sample_idx[k]])
                 q_eq += int(int(r["scalars"][1]) == int(gpu["quality"][sample_idx[k]]))
+                ne_eq += int(int(r["scalars"][2]) == int(gpu["nerr"][sample_idx[k]]))
+                ne_ref += int(r["scalars"][2]); ne_gpu += int(gpu["nerr"][sample_idx[k]])
             errs = np.array(errs)
             parity = {"against": "reference Fortran/DLSODES end states of the cpu_baseline sample, same RTOL (%g); species with X >= 1e-6" % params.RTOL,
                       "cells": nsample, "max_rel_err": float(errs.max()), "median_rel_err": float(np.median(errs)),
                       "p90_rel_err": float(np.percentile(errs, 90)), "cells_within_1e-4": int((errs <= 1e-4).sum()),
                       "t_final_equal": tf_eq, "quality_equal": q_eq,
+                      "nerr_equal": ne_eq, "nerr_total_reference": ne_ref, "nerr_total_gpu": ne_gpu,  # error returns (ISTATE < 0) of the integrator
                       "note": "at RTOL 1e-4 the reference moves by 1e-5...1e-3 against its own 1-ulp-perturbed twin (tests/golden yend_ulp); "
                               "the RTOL 1e-8 pin (<= 2e-6) is tests/test_gpu_parity.py::test_tight_tolerance_run_matches_the_reference_truth"}
             if tight is not None:  # the same comparison where trajectory noise does not limit it: RTOL 1e-8 on both sides
@@ -373,7 +376,7 @@ def main():
             cores = min(os.cpu_count() or 1, 16)
             nsample = min(ncell, 16 * cores)
             sample_idx = np.arange(nsample) * (ncell // nsample) + (ncell // nsample) // 2  # spread over the whole batch
-            gpu = {"y": y_d.cpu().numpy(), "t_final": tfin_d.cpu().numpy(), "quality": qual, "nst": stats[:, 0]}
+            gpu = {"y": y_d.cpu().numpy(), "t_final": tfin_d.cpu().numpy(), "quality": qual, "nst": stats[:, 0], "nerr": stats[:, R.S_NERR]}
             tidx = sample_idx[::max(1, nsample // 32)][:32]
             p8 = R.default_params()
             for f in ("ATOL", "t_max", "dt_first_step", "ratio_tstep", "mxstep_per_interval", "steps_reset_solver"):

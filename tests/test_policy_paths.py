@@ -137,6 +137,9 @@ def test_gpu_grid_cells_side_effects_and_tmax(racgpu):
         assert out["quality"][k] == int(G["grid_scalars"][k, 1])
         assert out["stats"][k, racgpu.S_NREC_REAL] == int(G["grid_stats"][k, 8])
         assert out["stats"][k, racgpu.S_ISAV] == out["stats"][k, racgpu.S_NREC_REAL]
+        # error returns: cell 14998 takes one ISTATE = -5 in the reference (gH loosened, src/chemistry.f90:352-377); where exactly a
+        # corrector gives up is rounding-sensitive, so the count may differ by one
+        assert abs(out["stats"][k, racgpu.S_NERR] - int(G["grid_scalars"][k, 2])) <= 1
         np.testing.assert_allclose(out["cell_out"][k, racgpu.O_R_H2_FORM], G["grid_side"][k, 0], rtol=1e-12)
         # n_mol_on_grain is a sum over the surface species of the end state: as close to the reference as the end state is
         np.testing.assert_allclose(out["cell_out"][k, racgpu.O_N_MOL_ON_GRAIN], G["grid_side"][k, 1], rtol=1e-3)
