@@ -1,5 +1,5 @@
-"""BASELINE configs[1] at its full size (10 000 synthetic cells, rate06 no-grain) on the GPU, checked through
-properties that do not need a reference run of 10 000 cells:
+"""BASELINE configs[1] (10 000 synthetic cells, rate06 no-grain) and configs[2] (the 20 000-cell Andrews grid, rate06 with grains:
+the headline workload) at their full sizes on the GPU, checked through properties that do not need a reference run of every cell:
 
 * element conservation and charge neutrality, for the columns of the reference's element matrix that every
   reaction of the network balances.  A BDF step with a Newton corrector preserves such linear invariants up to the
@@ -127,3 +127,80 @@ def test_other_networks_batch_properties(racgpu, oracle, netfile, inifile):
         assert np.all(drift <= bound), (e, float(drift.max()), float((drift / bound).max()))
     alone = net.evol_solve_batch(p, cells[100:108], yin[100:108])
     np.testing.assert_array_equal(alone["y"], out["y"][100:108])
+
+
+# ---- BASELINE configs[2], the headline workload: the full 20 000-cell Andrews grid on the rate06+grain network ---------------------
+@pytest.fixture(scope="module")
+def grid(racgpu):
+    net = racgpu.Network(f"{DATA}/rate06_dipole_reformated_again_withgrain_lowH2Bind.dat")
+    y0 = net.load_initial_abundances(f"{DATA}/ini_abund_waterice_loMetal.dat")
+    cells = racgpu.cells.andrews_grid()
+    p = racgpu.default_params()
+    yin = net.init_abundances(y0, cells)
+    out = net.evol_solve_batch(p, cells, yin)
+    return net, cells, p, yin, out
+
+
+def test_grid_every_cell_reaches_its_own_tmax(grid, racgpu):
+    net, cells, p, yin, out = grid
+    assert len(cells) == 20000
+    tmax = cells[:, racgpu.cells.P_TMAX]
+    assert tmax.min() < 1e4 and (tmax == p.t_max).sum() > 5000  # the orbit rule gives the inner columns shorter runs
+    assert np.all(out["quality"] == 0), np.unique(out["quality"], return_counts=True)
+    st = out["stats"]
+    # a cell without error returns ends exactly at its t_max; one that took an ISTATE < 0 return lags by what that interval lost
+    # and may run out of records a fraction of a per cent early (chem_evol_solve's loop, reference src/chemistry.f90:440-565: the
+    # reference's own cells do the same, on other cells)
+    clean = st[:, racgpu.S_NERR] == 0
+    assert clean.sum() > 0.85 * len(cells)
+    assert np.all(out["t_final"][clean] == tmax[clean])
+    short = out["t_final"] != tmax
+    assert short.sum() <= 30 and np.all(out["t_final"] >= 0.9 * tmax), (int(short.sum()), float((out["t_final"] / tmax).min()), st[short][:, [racgpu.S_NERR]].ravel())
+    assert np.all(st[:, racgpu.S_ISAV] == st[:, racgpu.S_NREC_REAL]) and np.all(st[:, racgpu.S_NREC_REAL] == st[:, racgpu.S_NREC])
+    assert np.all(np.isfinite(out["y"])) and np.all(np.isfinite(out["cell_out"]))
+    # n_mol_on_grain is the sum of the surface species per grain (get_ice_coverage, reference src/chemistry.f90:989-1003)
+    at_grain = np.array([nm.startswith("g") for nm in net.names])
+    np.testing.assert_allclose(out["cell_out"][:, racgpu.O_N_MOL_ON_GRAIN], out["y"][:, at_grain].sum(axis=1) / cells[:, racgpu.cells.P_D2H], rtol=1e-12)
+    # no cell is a tail: the costliest one stays within a few times the mean
+    cyc = st[:, racgpu.S_CYC_TOTAL].astype(float)
+    assert cyc.max() < 4.0 * cyc.mean()
+
+
+def test_grid_elements_and_charge_are_conserved(grid, oracle):
+    net, cells, p, yin, out = grid
+    onet = oracle.Network(f"{DATA}/rate06_dipole_reformated_again_withgrain_lowH2Bind.dat")
+    el = onet.elements.astype(np.float64)
+    balance = np.zeros((onet.nR, el.shape[1]))
+    for k in range(3):
+        m = onet.reac[:, k] > 0
+        balance[m] -= el[onet.reac[m, k] - 1]
+    for k in range(4):
+        m = onet.prod[:, k] > 0
+        balance[m] += el[onet.prod[m, k] - 1]
+    balanced = [e for e in range(el.shape[1]) if np.any(el[:, e]) and not np.any(balance[:, e])]
+    assert 0 in balanced and len(balanced) >= 8, balanced
+    before, after = yin @ el, out["y"] @ el
+    tot = np.maximum(np.abs(yin) @ np.abs(el), np.abs(out["y"]) @ np.abs(el))
+    for e in balanced:
+        drift = np.abs(after[:, e] - before[:, e])
+        bound = 1e-6 * tot[:, e] + 1e-7
+        assert np.all(drift <= bound), (e, float(drift.max()), float((drift / bound).max()))
+
+
+def test_grid_cells_do_not_care_where_or_when_they_are_solved(grid, racgpu):
+    net, cells, p, yin, out = grid
+    pick = np.arange(0, 20000, 313)  # 64 cells from all over the grid, solved as a batch of their own
+    alone = net.evol_solve_batch(p, cells[pick], yin[pick])
+    np.testing.assert_array_equal(alone["y"], out["y"][pick])
+    np.testing.assert_array_equal(alone["t_final"], out["t_final"][pick])
+    net.set_cost_hints(out["stats"][:, racgpu.S_CYC_TOTAL].astype(np.float64))
+    try:
+        again = net.evol_solve_batch(p, cells, yin)
+    finally:
+        net.set_cost_hints(None)
+    np.testing.assert_array_equal(again["y"], out["y"])
+    np.testing.assert_array_equal(again["stats"][:, :8], out["stats"][:, :8])
+    # the caller's loop has nothing to redo on this workload: one local iteration everywhere, same bits
+    loop = net.calc_cells(p, cells[pick], yin[pick], nlocal_iter=4)
+    np.testing.assert_array_equal(loop["y"], out["y"][pick])
+    assert np.all(loop["stats"][:, racgpu.S_NITER] == 1)
