@@ -62,11 +62,8 @@ template <typename V>
 RG_DEV double dev_vnorm(const CellCtx &c, V v) { // DVNORM over NEQ = nS+1 entries, the T entry being zero
   double s = 0.0;
   const rsrc_t bE = mkbuf(c.ewt);
-  for (int i0 = 0; i0 < c.n; i0 += 64) {
-    const double e = bload_f64(bE, c.lane * 8, i0 * 8);
-    const int i = i0 + c.lane;
-    if (i < c.n) { const double q = v(i) * e; s += q * q; }
-  }
+  vec_trips<4, double>(c.n, c.npad, [&](int i0) { return bload_f64(bE, c.lane * 8, i0 * 8); },
+                       [&](int i0, double e) { const int i = i0 + c.lane; if (i < c.n) { const double q = v(i) * e; s += q * q; } });
   return sqrt(wave_sum(s) * g_wc.inv_neq);
 }
 
@@ -83,6 +80,23 @@ RG_DEV void dev_set_order(const DevParams &P, Lsodes &s) { // DSTODE label 150
 // only HBM is involved; entries >= n of a column are never used.
 RG_DEV int col_off(const CellCtx &c, int j) { return j * c.npad * 8; } // byte offset of Nordsieck column j (0-based)
 
+// Block loops over these vectors run B blocks of 64 per trip with all loads of a trip issued before anything is used: a loop
+// whose trip count the compiler does not know is not unrolled, and every block would otherwise wait out its own round trip to
+// HBM/L2.  ld(i0) fetches what block i0 needs (blocks past the end re-read the last one), use(i0, v) is called for i0 < n.
+template <int B, typename T, typename LD, typename USE>
+RG_DEV void vec_trips(int n, int npad, LD ld, USE use) {
+  for (int c0 = 0; c0 < n; c0 += 64 * B) {
+    T v[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) v[u] = ld(min(c0 + 64 * u, npad - 64));
+#pragma unroll
+    for (int u = 0; u < B; ++u) if (c0 + 64 * u < n) use(c0 + 64 * u, v[u]);
+  }
+}
+struct D2 { double a, b; };
+struct D3 { double a, b, c; };
+struct DCols { double v[kMaxord + 2]; }; // the Nordsieck columns of one block (+ one more vector)
+
 RG_DEV void dev_rescale(const CellCtx &c, Lsodes &s, double rh, bool apply_hmin) { // DSTODE labels 170/175
   if (apply_hmin) rh = fmax(rh, 0.0); // RH = MAX(RH, HMIN/ABS(H)) with HMIN = 0
   rh = fmin(rh, s.rmax);
@@ -93,7 +107,7 @@ RG_DEV void dev_rescale(const CellCtx &c, Lsodes &s, double rh, bool apply_hmin)
   for (int j = 2; j <= s.l; ++j) {
     r = r * rh;
     const int co = col_off(c, j - 1);
-    for (int i0 = 0; i0 < c.n; i0 += 64) bstore_f64(bY, l8, co + i0 * 8, bload_f64(bY, l8, co + i0 * 8) * r);
+    vec_trips<4, double>(c.n, c.npad, [&](int i0) { return bload_f64(bY, l8, co + i0 * 8); }, [&](int i0, double v) { bstore_f64(bY, l8, co + i0 * 8, v * r); });
   }
   s.h = s.h * rh; s.rc = s.rc * rh; s.ialth = s.l;
 }
@@ -103,21 +117,25 @@ RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward) {
   const int nq = s.nq;
   const rsrc_t bY = mkbuf(c.yh);
   const int l8 = c.lane * 8;
-  for (int i0 = 0; i0 < c.n; i0 += 64) {
-    double col[kMaxord + 1];
+  vec_trips<2, DCols>(c.n, c.npad,
+    [&](int i0) {
+      DCols d;
 #pragma unroll
-    for (int j = 0; j <= kMaxord; ++j) col[j] = (j <= nq) ? bload_f64(bY, l8, col_off(c, j) + i0 * 8) : 0.0;
+      for (int j = 0; j <= kMaxord; ++j) d.v[j] = (j <= nq) ? bload_f64(bY, l8, col_off(c, j) + i0 * 8) : 0.0;
+      return d;
+    },
+    [&](int i0, DCols d) {
 #pragma unroll
-    for (int jb = 1; jb <= kMaxord; ++jb) {
-      if (jb > nq) break;
+      for (int jb = 1; jb <= kMaxord; ++jb) {
+        if (jb > nq) break;
+#pragma unroll
+        for (int j = 0; j < kMaxord; ++j)
+          if (j >= nq - jb && j < nq) d.v[j] = forward ? d.v[j] + d.v[j + 1] : d.v[j] - d.v[j + 1];
+      }
 #pragma unroll
       for (int j = 0; j < kMaxord; ++j)
-        if (j >= nq - jb && j < nq) col[j] = forward ? col[j] + col[j + 1] : col[j] - col[j + 1];
-    }
-#pragma unroll
-    for (int j = 0; j < kMaxord; ++j)
-      if (j < nq) bstore_f64(bY, l8, col_off(c, j) + i0 * 8, col[j]);
-  }
+        if (j < nq) bstore_f64(bY, l8, col_off(c, j) + i0 * 8, d.v[j]);
+    });
 }
 
 // DPRJS for MITER = 1.  y (LDS) holds the predicted values.
@@ -195,7 +213,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     bool converged = false;
     for (int pass = 0; pass < 4; ++pass) { // label 220: re-entered after a P refresh (at most twice: rescaled P, then fresh J)
       m = 0;
-      for (int i0 = 0; i0 < n; i0 += 64) { const double v = bload_f64(bY, l8, i0 * 8); if (i0 + lane < n) c.y[i0 + lane] = v; }
+      vec_trips<4, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
       { const long long t0 = dev_clock(); dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
       dev_mark(c, 2200 + pass);
       if (s.ipup > 0) {
@@ -207,21 +225,15 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bA, l8, i0 * 8, 0.0);
       bool fail410 = false;
       for (;;) {
-        for (int i0 = 0; i0 < n; i0 += 64) {
-          const double y1 = bload_f64(bY, l8, col_off(c, 1) + i0 * 8), ac = bload_f64(bA, l8, i0 * 8);
-          const int i = i0 + lane;
-          if (i < n) c.y[i] = s.h * c.savf[i] - (y1 + ac);
-        }
+        vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
+                         [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) c.y[i] = s.h * c.savf[i] - (v.a + v.b); });
         dev_mark(c, 2400 + m);
         { const long long t0 = dev_clock(); dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane); cyc_add(CYC_SOLVE, dev_clock() - t0); }
         dev_mark(c, 2500 + m);
         del = dev_vnorm(c, [&](int i) { return c.y[i]; });
         const double el1 = P.elco[s.nq][1];
-        for (int i0 = 0; i0 < n; i0 += 64) {
-          const double y0 = bload_f64(bY, l8, i0 * 8), ac = bload_f64(bA, l8, i0 * 8);
-          const int i = i0 + lane;
-          if (i < n) { const double a = ac + c.y[i]; bstore_f64(bA, l8, i0 * 8, a); c.y[i] = y0 + el1 * a; }
-        }
+        vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
+                         [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) { const double a = v.b + c.y[i]; bstore_f64(bA, l8, i0 * 8, a); c.y[i] = v.a + el1 * a; } });
         if (m != 0) s.crate = fmax(0.2 * s.crate, del / delp);
         const double dcon = del * fmin(1.0, 1.5 * s.crate) / (P.tesco[s.nq][2] * s.conit);
         if (dcon <= 1.0) { converged = true; break; }
@@ -250,10 +262,8 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     if (m == 0) dsm = del / P.tesco[s.nq][2];
     else {
       double q = 0.0;
-      for (int i0 = 0; i0 < n; i0 += 64) {
-        const double w = bload_f64(bA, l8, i0 * 8) * bload_f64(bE, l8, i0 * 8);
-        if (i0 + lane < n) q += w * w;
-      }
+      vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bA, l8, i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
+                       [&](int i0, D2 v) { const double w = v.a * v.b; if (i0 + lane < n) q += w * w; });
       dsm = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][2];
     }
 
@@ -268,7 +278,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (s.kflag == -10) { s.kflag = -1; break; }
         rh = 0.1;
         s.h = s.h * rh;
-        for (int i0 = 0; i0 < n; i0 += 64) { const double v = bload_f64(bY, l8, i0 * 8); if (i0 + lane < n) c.y[i0 + lane] = v; }
+        vec_trips<4, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
         dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe++;
         for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, 1) + i0 * 8, s.h * c.savf[i]); }
         s.ipup = 1; s.ialth = 5;
@@ -278,22 +288,31 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       iredo = 2; rhup = 0.0; consider = true;
     } else {
       s.kflag = 0; iredo = 0; s.nst++; s.hu = s.h; s.nqu = s.nq; s.qsum += s.nq;
-      for (int i0 = 0; i0 < n; i0 += 64) { // element-outer: acor is read once per block
-        const double ac = bload_f64(bA, l8, i0 * 8);
-        for (int j = 1; j <= s.l; ++j) {
-          const int o = col_off(c, j - 1) + i0 * 8;
-          bstore_f64(bY, l8, o, bload_f64(bY, l8, o) + P.elco[s.nq][j] * ac);
-        }
+      {
+        const int l = s.l;
+        double el[kMaxord + 1];
+#pragma unroll
+        for (int j = 0; j <= kMaxord; ++j) el[j] = (j < l) ? P.elco[s.nq][j + 1] : 0.0;
+        vec_trips<2, DCols>(n, c.npad,
+          [&](int i0) { // acor is read once per block
+            DCols d;
+#pragma unroll
+            for (int j = 0; j <= kMaxord; ++j) d.v[j] = (j < l) ? bload_f64(bY, l8, col_off(c, j) + i0 * 8) : 0.0;
+            d.v[kMaxord + 1] = bload_f64(bA, l8, i0 * 8);
+            return d;
+          },
+          [&](int i0, DCols d) {
+#pragma unroll
+            for (int j = 0; j <= kMaxord; ++j)
+              if (j < l) bstore_f64(bY, l8, col_off(c, j) + i0 * 8, d.v[j] + el[j] * d.v[kMaxord + 1]);
+          });
       }
       s.ialth--;
       if (s.ialth == 0) { // label 520
         rhup = 0.0;
         if (s.l != s.lmax) {
-          for (int i0 = 0; i0 < n; i0 += 64) {
-            const double top = bload_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8);
-            const int i = i0 + lane;
-            if (i < n) c.savf[i] = bload_f64(bA, l8, i0 * 8) - top;
-          }
+          vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
+                           [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) c.savf[i] = v.b - v.a; });
           const double dup = dev_vnorm(c, [&](int i) { return c.savf[i]; }) / P.tesco[s.nq][3];
           const double exup = 1.0 / (s.l + 1);
           rhup = 1.0 / (1.4 * pow(dup, exup) + 0.0000014);
@@ -313,10 +332,8 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       double rhdn = 0.0;
       if (s.nq != 1) {
         double q = 0.0;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-          const double w = bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8) * bload_f64(bE, l8, i0 * 8);
-          if (i0 + lane < n) q += w * w;
-        }
+        vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
+                         [&](int i0, D2 v) { const double w = v.a * v.b; if (i0 + lane < n) q += w * w; });
         const double ddn = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][1];
         const double exdn = 1.0 / s.nq;
         rhdn = 1.0 / (1.3 * pow(ddn, exdn) + 0.0000013);
@@ -347,7 +364,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
 
 done700: {
     const double r = 1.0 / P.tesco[s.nqu][2];
-    for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bA, l8, i0 * 8, bload_f64(bA, l8, i0 * 8) * r);
+    vec_trips<4, double>(n, c.npad, [&](int i0) { return bload_f64(bA, l8, i0 * 8); }, [&](int i0, double v) { bstore_f64(bA, l8, i0 * 8, v * r); });
   }
   s.hold = s.h; s.jstart = 1;
   return s.kflag;
@@ -357,22 +374,32 @@ RG_DEV void dev_intdy0(const CellCtx &c, const Lsodes &s, double t) { // y <- in
   const double sf = (t - s.tn) / s.h;
   const rsrc_t bY = mkbuf(c.yh);
   const int l8 = c.lane * 8;
-  for (int i0 = 0; i0 < c.n; i0 += 64) {
-    double d = bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8);
-    for (int j = s.nq - 1; j >= 0; --j) d = bload_f64(bY, l8, col_off(c, j) + i0 * 8) + sf * d;
-    if (i0 + c.lane < c.n) c.y[i0 + c.lane] = d;
-  }
+  const int nq = s.nq;
+  vec_trips<2, DCols>(c.n, c.npad,
+    [&](int i0) {
+      DCols d;
+#pragma unroll
+      for (int j = 0; j <= kMaxord; ++j) d.v[j] = (j <= nq) ? bload_f64(bY, l8, col_off(c, j) + i0 * 8) : 0.0;
+      return d;
+    },
+    [&](int i0, DCols v) {
+      double d = 0.0; // Horner from column nq down; the columns above nq were loaded as zeros
+#pragma unroll
+      for (int j = kMaxord; j >= 0; --j) d = (j <= nq) ? ((j == nq) ? v.v[j] : v.v[j] + sf * d) : d;
+      if (i0 + c.lane < c.n) c.y[i0 + c.lane] = d;
+    });
 }
 
 RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some weight is <= 0
   bool bad = false;
   const rsrc_t bY = mkbuf(c.yh), bR = mkbuf(c.rtol), bA = mkbuf(c.atol), bE = mkbuf(c.ewt);
   const int l8 = c.lane * 8;
-  for (int i0 = 0; i0 < c.n; i0 += 64) {
-    const double e = bload_f64(bR, l8, i0 * 8) * fabs(bload_f64(bY, l8, i0 * 8)) + bload_f64(bA, l8, i0 * 8);
-    if (i0 + c.lane < c.n && e <= 0.0) bad = true;
-    bstore_f64(bE, l8, i0 * 8, 1.0 / e);
-  }
+  vec_trips<4, D3>(c.n, c.npad, [&](int i0) { return D3{bload_f64(bR, l8, i0 * 8), bload_f64(bY, l8, i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
+                   [&](int i0, D3 v) {
+                     const double e = v.a * fabs(v.b) + v.c;
+                     if (i0 + c.lane < c.n && e <= 0.0) bad = true;
+                     bstore_f64(bE, l8, i0 * 8, 1.0 / e);
+                   });
   const double Tg = g_wc.Tgas, eT = g_wc.rT * fabs(Tg) + g_wc.aT;
   if (eT <= 0.0) bad = true;
   return !wave_any(bad);
@@ -380,7 +407,7 @@ RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some w
 
 RG_DEV void dev_finish(const CellCtx &c, const Lsodes &s, double &t) { // label 580 / 400
   const rsrc_t bY = mkbuf(c.yh);
-  for (int i0 = 0; i0 < c.n; i0 += 64) { const double v = bload_f64(bY, c.lane * 8, i0 * 8); if (i0 + c.lane < c.n) c.y[i0 + c.lane] = v; }
+  vec_trips<4, double>(c.n, c.npad, [&](int i0) { return bload_f64(bY, c.lane * 8, i0 * 8); }, [&](int i0, double v) { if (i0 + c.lane < c.n) c.y[i0 + c.lane] = v; });
   t = s.tn;
 }
 
@@ -471,10 +498,8 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
     first = false;
     {
       double q = 0.0;
-      for (int i0 = 0; i0 < n; i0 += 64) {
-        const double v = bload_f64(bY, l8, i0 * 8) * bload_f64(bE, l8, i0 * 8);
-        if (i0 + lane < n) q += v * v;
-      }
+      vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
+                       [&](int i0, D2 w) { const double v = w.a * w.b; if (i0 + lane < n) q += v * v; });
       const double Tg = g_wc.Tgas, vT = Tg / (g_wc.rT * fabs(Tg) + g_wc.aT);
       const double tolsf = u * sqrt((wave_sum(q) + vT * vT) * g_wc.inv_neq);
       if (tolsf > 1.0) {
