@@ -202,6 +202,12 @@ int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
  * cells that need many times the median work start first instead of last.  Results do not depend on the order.
  * The hint applies while ncell matches; cost == NULL or ncell == 0 clears it. */
 int racgpu_set_cost_hints(racgpu_network *, const double *cost, int64_t ncell);
+/* With cost hints in place, a cell whose expected cost exceeds frac x (sum of the costs / wave slots of the GPU) -- a cell that
+ * would take that share of the pass's ideal length all by itself -- is solved by a team of four waves (at most one team per CU),
+ * started ahead of the rest.  Same arithmetic in the same order: results do not depend on it.  Default 0.5; frac <= 0: never. */
+int racgpu_set_team_threshold(racgpu_network *, double frac);
+/* cells the last solve pass gave to teams */
+int64_t racgpu_last_team_cells(const racgpu_network *);
 /* bytes of device workspace racgpu_solve_batch keeps per cell (grows the handle's workspace on demand) */
 int64_t racgpu_workspace_bytes_per_cell(const racgpu_network *);
 /* HIP-event time of the last racgpu_solve_batch kernel on its stream, milliseconds (-1 if none) */

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
     "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_rectify_abundances",
-    "racgpu_set_cost_hints", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
+    "racgpu_set_cost_hints", "racgpu_set_team_threshold", "racgpu_last_team_cells", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
 ]
 
 
@@ -112,6 +112,10 @@ def lib():
     L.racgpu_set_cost_hints.argtypes = [vp, dp, C.c_int64]
     L.racgpu_last_kernel_ms.restype = C.c_double
     L.racgpu_last_kernel_ms.argtypes = [vp]
+    L.racgpu_set_team_threshold.restype = C.c_int
+    L.racgpu_set_team_threshold.argtypes = [vp, C.c_double]
+    L.racgpu_last_team_cells.restype = C.c_int64
+    L.racgpu_last_team_cells.argtypes = [vp]
     _lib = L
     return L
 
@@ -328,6 +332,15 @@ class Network:
             return
         cost = np.ascontiguousarray(cost, dtype=np.float64).ravel()
         _check(lib().racgpu_set_cost_hints(self._h, cost.ctypes.data_as(C.POINTER(C.c_double)), cost.size))
+
+    def set_team_threshold(self, frac):
+        """With cost hints: cells expected to cost more than frac x (sum of costs / wave slots) are solved by four waves each
+        (racgpu_set_team_threshold; default 0.5, <= 0 never).  Results do not depend on it."""
+        _check(lib().racgpu_set_team_threshold(self._h, float(frac)))
+
+    def last_team_cells(self):
+        """cells the last solve pass gave to four-wave teams"""
+        return int(lib().racgpu_last_team_cells(self._h))
 
     def last_kernel_ms(self):
         return lib().racgpu_last_kernel_ms(self._h)

@@ -52,6 +52,7 @@ struct DevNet {
   const uint64_t *jac_stream, *jac_slot;
   const uint32_t *jac_rowflag;
   int jac_rows;
+  int jac_seg_row[5], jac_seg_pass[5]; // the stream in four segments of whole passes (first row / first pass; [4] = the end): k_solve_team
   // ---- sparse LU of the permuted species block ----
   const uint16_t *perm;      // perm[new] = old
   const uint16_t *Lrow, *Urow, *Prow; // storage layout: see network.hpp, struct Symbolic

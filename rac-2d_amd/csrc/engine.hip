@@ -111,14 +111,20 @@ struct SolveArgs {
   const int *tolj;                  // [ncell] or null (DevParams::tol_j)
   double *t_final; int *quality; long long *stats; double *record, *touts, *cell_out;
   const int *order;                 // queue order or null
+  int slot0;                        // this launch's first workspace slot
 };
 
-__global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
-  extern __shared__ double lds[];
-  const DevNet &N = *Np; const DevParams &P = *Pp;
-  const int lane = threadIdx.x, slot = blockIdx.x, n = N.nS, nlds = (n + 1) & ~1;
+// TEAM = 1: one wave per workgroup and per cell (k_solve, the bulk of a batch).  TEAM = 4 (k_solve_team): four waves per cell for
+// the few cells that would otherwise set the length of the pass on their own; wave 0 runs the integrator exactly as with TEAM =
+// 1, the others wait at a barrier for the parts that are shared out (the factorisation, dev_lu's team mode) -- same arithmetic
+// in the same order per column, same results to the last bit.
+template <int TEAM>
+RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, const SolveArgs &A, double *lds) {
+  const int lane = threadIdx.x & 63, wv = TEAM > 1 ? uniform_i((int)(threadIdx.x >> 6)) : 0;
+  const int slot = A.slot0 + blockIdx.x, n = N.nS, nlds = (n + 1) & ~1;
   LdsViews v = carve(lds, nlds);
   CellCtx c;
+  c.nteam = TEAM;
   c.y = v.y; c.savf = v.savf; c.wx = v.wx;
   c.acor = W.acor + (size_t)slot * N.npad; c.ewt = W.ewt + (size_t)slot * N.npad;
   c.rates = nullptr; c.yh = W.yh + (size_t)slot * 6 * N.npad; c.Pv = W.P + (size_t)slot * N.nnzJ;
@@ -127,7 +133,21 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
   double *ygood = W.ygood + (size_t)slot * N.npad;
   c.lane = lane; c.n = n; c.npad = N.npad;
   c.marker = slot == 0 ? W.marker : nullptr;
+  if (TEAM > 1 && wv != 0) { // a helper wave: serve wave 0's requests until it has no more cells
+    double *hw = lds + 3 * nlds + 64 + (wv - 1) * (nlds + 64); // work column + one spare double per lane
+    for (;;) {
+      team_barrier();
+      const int cmd = g_team.cmd;
+      if (cmd == T_EXIT) return;
+      if (cmd == T_LU) dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, hw, c.y, lane, nullptr, hw + nlds, wv, TEAM, &g_team.fail);
+      if (cmd == T_JAC) {
+        dev_build_P<true>(N, W.rates + (size_t)g_team.cell * N.nR, g_wc.nsite, c.y, g_team.con, true, c.Pv, lane, wv);
+        team_barrier();
+      }
+    }
+  }
   g_wc.inv_neq = 1.0 / (double)(n + 1);
+  if (TEAM > 1 && lane == 0) atomicAdd(W.counter - 1, 1); // k_gate: this workgroup is resident (the team queue's counter is word [2], this is [1])
   for (;;) {
     int cell = 0;
     if (lane == 0) cell = atomicAdd(W.counter, 1);
@@ -151,6 +171,7 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
     { double rT, aT; dev_tolerances(N, P, A.tolj ? A.tolj[cell] : P.tol_j, cp[RACGPU_P_D2H], c.rtol, c.atol, rT, aT, lane); g_wc.rT = rT; g_wc.aT = aT; }
     dev_mark(c, 2);
     c.rates = W.rates + (size_t)cell * N.nR; // filled by k_rates for the whole batch just before this launch
+    if (TEAM > 1) g_team.cell = cell;
     dev_mark(c, 3);
     for (int i = lane; i < n; i += 64) c.y[i] = A.yio[(size_t)cell * n + i];
     wave_sync();
@@ -200,6 +221,28 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
     dev_mark(c, 6);
   }
   dev_mark(c, 7);
+  if (TEAM > 1) { g_team.cmd = T_EXIT; team_barrier(); }
+}
+
+__global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
+  extern __shared__ double lds[];
+  solve_body<1>(*Np, *Pp, W, A, lds);
+}
+
+constexpr int kTeam = 4;
+__global__ __launch_bounds__(64 * kTeam) void k_solve_team(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
+  extern __shared__ double lds[];
+  solve_body<kTeam>(*Np, *Pp, W, A, lds);
+}
+
+// Holds the stream that launches the bulk kernel until the team kernel's workgroups have started (or a bound of ~20 ms has passed:
+// the gate can delay, never hang).  The bulk kernel's persistent waves fill every wave slot of the chip and keep it until the queue is
+// empty; team workgroups dispatched after them would only start once the pass is all but over.
+__global__ void k_gate(const int *started, int want, long long max_cycles) {
+  const long long t0 = (long long)__builtin_readcyclecounter();
+  while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
+         (long long)__builtin_readcyclecounter() - t0 < max_cycles)
+    __builtin_amdgcn_s_sleep(64);
 }
 
 // ---- the caller's retry loop over local iterations (calc_this_cell, reference src/disk.f90:1651-1791), batched -----
@@ -264,6 +307,10 @@ struct racgpu_network {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<double> cost_hints; // racgpu_set_cost_hints
   int *order_dev = nullptr; long order_cap = 0;
+  std::vector<int> order_host;    // the queue order of the last hinted pass
+  double team_frac = 0.5;         // racgpu_set_team_threshold
+  hipStream_t team_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  long last_team_cells = 0;       // cells the last pass solved four waves at a time
   bool timed = false;
   int cu_count = 0;
 
@@ -289,6 +336,9 @@ struct racgpu_network {
     for (void *p : dev_allocs) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (team_stream) (void)hipStreamDestroy(team_stream);
   }
 };
 
@@ -380,7 +430,27 @@ void racgpu_network::upload() {
       const int npass = (int)order.size() / 64;
       std::vector<uint64_t> stream, slot((size_t)(npass + 1) * 64, 0ull);
       std::vector<uint32_t> rowflag;
+      // k_solve_team shares the stream out over its waves: kTeam segments of whole passes with about the same number of rows; a
+      // segment starts on a multiple of kJacUnroll rows (the pass before it is padded with null rows, its "last row" flag moves)
+      long rows_total = 0;
+      std::vector<int> pass_rows(npass, 1);
       for (int p = 0; p < npass; ++p) {
+        for (int l = 0; l < 64; ++l) {
+          const int e = order[(size_t)p * 64 + l];
+          if (e >= 0) pass_rows[p] = std::max(pass_rows[p], h.term_ptr[e + 1] - h.term_ptr[e]);
+        }
+        rows_total += pass_rows[p];
+      }
+      int seg = 1; long rows_done = 0;
+      dn.jac_seg_row[0] = 0; dn.jac_seg_pass[0] = 0;
+      for (int p = 0; p < npass; ++p) {
+        if (seg < kTeam && rows_done >= rows_total * seg / kTeam) { // pass p opens segment seg
+          while (rowflag.size() % kJacUnroll) {
+            rowflag.back() = 0u; rowflag.push_back(1u); stream.insert(stream.end(), 64, ~0ull);
+          }
+          dn.jac_seg_row[seg] = (int)rowflag.size(); dn.jac_seg_pass[seg] = p; ++seg;
+        }
+        rows_done += pass_rows[p];
         int niter = 1;
         for (int l = 0; l < 64; ++l) {
           const int e = order[(size_t)p * 64 + l];
@@ -399,6 +469,7 @@ void racgpu_network::upload() {
       }
       while (rowflag.size() % kJacUnroll) { rowflag.push_back(0u); stream.insert(stream.end(), 64, ~0ull); }
       dn.jac_rows = (int)rowflag.size();
+      for (; seg <= kTeam; ++seg) { dn.jac_seg_row[seg] = dn.jac_rows; dn.jac_seg_pass[seg] = npass; } // (fewer passes than waves: empty segments)
       stream.insert(stream.end(), (size_t)64 * (kJacUnroll + 8), ~0ull); // the kernel prefetches rows past the end
       rowflag.resize((rowflag.size() + 63) / 64 * 64 + 64, 0u);
       dn.jac_stream = up(stream); dn.jac_rowflag = up(rowflag); dn.jac_slot = up(slot);
@@ -520,6 +591,9 @@ void racgpu_network::upload() {
     if (h.R[r].itype == 0 || (h.R[r].itype == 63 && h.R[r].rname[0] == "gH")) dn.r_h2form = r;
   HIP_OK(hipEventCreate(&ev0));
   HIP_OK(hipEventCreate(&ev1));
+  HIP_OK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  HIP_OK(hipStreamCreateWithFlags(&team_stream, hipStreamNonBlocking));
   { void *d = nullptr; HIP_OK(hipMalloc(&d, sizeof(DevNet))); HIP_OK(hipMemcpy(d, &dn, sizeof(DevNet), hipMemcpyHostToDevice)); dev_allocs.push_back(d); dn_dev = (DevNet *)d; }
   { void *d = nullptr; HIP_OK(hipMalloc(&d, sizeof(DevParams))); dev_allocs.push_back(d); dp_dev = (DevParams *)d; }
   uploaded = true;
@@ -770,6 +844,10 @@ int racgpu_set_stream(racgpu_network *h, void *s) {
   return 0;
 }
 
+static size_t lds_bytes_team(const DevNet &dn) { // + a work column and the spare doubles for each of the other waves
+  const size_t nlds = (dn.nS + 1) & ~1;
+  return (3 * nlds + 64 + (kTeam - 1) * (nlds + 64)) * sizeof(double);
+}
 static size_t lds_bytes(const DevNet &dn) { return (size_t)3 * ((dn.nS + 1) & ~1) * sizeof(double) + 64 * sizeof(double); } // + one spare double per lane behind the last vector
 
 int racgpu_rates(racgpu_network *h, const racgpu_params *p, const double *cells, int64_t ncell, double *rates) {
@@ -858,6 +936,14 @@ int racgpu_newton_solve(racgpu_network *h, const racgpu_params *p, const double 
   });
 }
 
+int racgpu_set_team_threshold(racgpu_network *h, double frac) {
+  if (!h) return fail("null network");
+  h->team_frac = frac;
+  return 0;
+}
+
+int64_t racgpu_last_team_cells(const racgpu_network *h) { return h ? h->last_team_cells : -1; }
+
 int racgpu_set_cost_hints(racgpu_network *h, const double *cost, int64_t ncell) {
   if (!h) return fail("null network");
   if (!cost || ncell <= 0) { h->cost_hints.clear(); return 0; }
@@ -894,9 +980,11 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
   const long per_cu = std::max<long>(1, std::min<long>(cap, (long)(160 * 1024 / (lds + 512))));
   const long slots = std::min<long>(ncell, per_cu * h->cu_count);
   const long chunk_cells = std::max<long>(slots, std::min<long>(ncell, (long)(8e9 / (8.0 * h->dn.nR)))); // <= 8 GB of rates
-  h->ensure_workspace(slots, chunk_cells);
   // optional longest-expected-first order, per chunk (indices relative to the chunk)
   const bool hinted = use_hints && (int64_t)h->cost_hints.size() == ncell;
+  const long team_cap = hinted && h->team_frac > 0.0 ? std::min<long>(h->cu_count, ncell) : 0; // at most one team per CU
+  h->ensure_workspace(slots + team_cap, chunk_cells);
+  h->last_team_cells = 0;
   if (hinted) {
     if (h->order_cap < ncell) {
       HIP_OK(hipStreamSynchronize(h->stream));
@@ -904,7 +992,8 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
       HIP_OK(hipMalloc((void **)&h->order_dev, (size_t)ncell * sizeof(int)));
       h->order_cap = ncell;
     }
-    std::vector<int> order((size_t)ncell);
+    std::vector<int> &order = h->order_host;
+    order.resize((size_t)ncell);
     for (long c0 = 0; c0 < ncell; c0 += chunk_cells) {
       const long nc = std::min<long>(chunk_cells, ncell - c0);
       for (long i = 0; i < nc; ++i) order[c0 + i] = (int)i;
@@ -922,7 +1011,7 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
                        B.cell_out ? B.cell_out + (size_t)c0 * RACGPU_NOUT : nullptr);
     HIP_OK(hipGetLastError());
     // pass 2: the persistent integrator
-    HIP_OK(hipMemsetAsync(h->ws.counter, 0, sizeof(int), h->stream));
+    HIP_OK(hipMemsetAsync(h->ws.counter, 0, 4 * sizeof(int), h->stream)); // [0] bulk queue, [1] team workgroups started, [2] team queue
     if (c0 == 0 && first_timed) HIP_OK(hipEventRecord(h->ev0, h->stream));
     SolveArgs A{};
     A.ncell = (int)nc; A.flags = flags; A.cells = cells_c; A.yio = B.y + (size_t)c0 * nS;
@@ -933,8 +1022,37 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
     A.touts = B.touts ? B.touts + (size_t)c0 * P.n_record : nullptr;
     A.cell_out = B.cell_out ? B.cell_out + (size_t)c0 * RACGPU_NOUT : nullptr;
     A.order = hinted ? h->order_dev + c0 : nullptr;
-    hipLaunchKernelGGL(k_solve, dim3((unsigned)std::min<long>(slots, nc)), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, A);
-    HIP_OK(hipGetLastError());
+    A.slot0 = 0;
+    // Cells that would take more than team_frac of the pass's ideal length on their own (sum of costs / wave slots) go to
+    // k_solve_team, four waves each, on a second stream and ahead of the bulk kernel; they are the head of the sorted order.
+    long nteamc = 0;
+    if (team_cap > 0) {
+      const double *cost = h->cost_hints.data() + c0;
+      double total = 0.0;
+      for (long i = 0; i < nc; ++i) total += cost[i];
+      const double thr = h->team_frac * total / (double)slots;
+      while (nteamc < std::min<long>(team_cap, nc) && cost[h->order_host[c0 + nteamc]] > thr) ++nteamc;
+    }
+    if (nteamc > 0) {
+      SolveArgs T = A;
+      T.ncell = (int)nteamc; T.slot0 = (int)slots;
+      DevWork Wt = h->ws;
+      Wt.counter = h->ws.counter + 2;
+      HIP_OK(hipEventRecord(h->ev_fork, h->stream));
+      HIP_OK(hipStreamWaitEvent(h->team_stream, h->ev_fork, 0));
+      hipLaunchKernelGGL(k_solve_team, dim3((unsigned)nteamc), dim3(64 * kTeam), lds_bytes_team(h->dn), h->team_stream, h->dn_dev, h->dp_dev, Wt, T);
+      HIP_OK(hipGetLastError());
+      HIP_OK(hipEventRecord(h->ev_join, h->team_stream));
+      hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int *)(h->ws.counter + 1), (int)nteamc, 48000000LL);
+      A.ncell = (int)(nc - nteamc); A.order += nteamc;
+      h->last_team_cells += nteamc;
+    }
+    if (A.ncell > 0) {
+      const long grid = std::max<long>(1, std::min<long>(slots - kTeam * nteamc, A.ncell));
+      hipLaunchKernelGGL(k_solve, dim3((unsigned)grid), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, A);
+      HIP_OK(hipGetLastError());
+    }
+    if (nteamc > 0) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   }
 }
 

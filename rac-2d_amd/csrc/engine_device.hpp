@@ -55,6 +55,25 @@ RG_DEV void sstore_f64(rsrc_t r, int voff, int soff, double v) {
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, RG_STREAM_AUX);
 }
+#ifndef RG_SOLVE_AUX
+#define RG_SOLVE_AUX 2 // cache policy of the factor streams in the triangular solves (read once per solve)
+#endif
+RG_DEV double tload_f64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, RG_SOLVE_AUX)); }
+#ifndef RG_RATE_AUX
+#define RG_RATE_AUX RG_STREAM_AUX // the rate vector as dev_rhs streams it
+#endif
+#ifndef RG_USTORE_AUX
+#define RG_USTORE_AUX RG_STREAM_AUX // U as the factorisation writes it (only the solves read it back)
+#endif
+#ifndef RG_PLOAD_AUX
+#define RG_PLOAD_AUX RG_STREAM_AUX // P as the factorisation reads it (once)
+#endif
+RG_DEV double kload_f64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, RG_RATE_AUX)); }
+RG_DEV double pload_f64(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, RG_PLOAD_AUX)); }
+RG_DEV void ustore_f64(rsrc_t r, int voff, int soff, double v) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, RG_USTORE_AUX);
+}
 RG_DEV double uniform_d(double v) {
   union { double d; int i[2]; } u; u.d = v;
   u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
@@ -250,14 +269,14 @@ RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double ns
   uint64_t w0[D], w1[D], w2[D];
   double kk[D];
 #pragma unroll
-  for (int s = 0; s < D - 1; ++s) { w0[s] = bload_u64(bW0, l8, s * 512); w1[s] = bload_u64(bW1, l8, s * 512); w2[s] = bload_u64(bW2, l8, s * 512); kk[s] = sload_f64(bK, l8, s * 512); }
+  for (int s = 0; s < D - 1; ++s) { w0[s] = bload_u64(bW0, l8, s * 512); w1[s] = bload_u64(bW1, l8, s * 512); w2[s] = bload_u64(bW2, l8, s * 512); kk[s] = kload_f64(bK, l8, s * 512); }
   for (int r0 = 0; r0 < N.nR; r0 += 64 * D) {
 #pragma unroll
     for (int s = 0; s < D; ++s) {
       const int rb = r0 + 64 * s; // rows rb >= nR are padding (kind 0, no targets)
       {
         const int nx = (rb + 64 * (D - 1)) * 8, sl = (s + D - 1) % D;
-        w0[sl] = bload_u64(bW0, l8, nx); w1[sl] = bload_u64(bW1, l8, nx); w2[sl] = bload_u64(bW2, l8, nx); kk[sl] = sload_f64(bK, l8, nx);
+        w0[sl] = bload_u64(bW0, l8, nx); w1[sl] = bload_u64(bW1, l8, nx); w2[sl] = bload_u64(bW2, l8, nx); kk[sl] = kload_f64(bK, l8, nx);
       }
       const uint64_t c0 = w0[s], c1 = w1[s], c2 = w2[s];
       const double k = kk[s];
@@ -308,8 +327,10 @@ RG_DEV double dev_dflux(uint64_t term, double k, const RG_GLOBAL double *__restr
 // is gathered 3 rows ahead, so the only waits left in the loop are the LDS reads of y.
 template <bool PERMUTED>
 RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, double nsite, const double *y, double con,
-                        bool add_identity, double *__restrict__ Pv, int lane) {
+                        bool add_identity, double *__restrict__ Pv, int lane, const int seg = -1) {
   // PERMUTED: write each entry at its place in the permuted-column storage the LU reads with unit stride
+  // seg >= 0: only the passes of that segment of the stream (one wave of a team; the entries are independent of each other)
+  const int row0 = seg < 0 ? 0 : N.jac_seg_row[seg], row1 = seg < 0 ? N.jac_rows : N.jac_seg_row[seg + 1], pass0 = seg < 0 ? 0 : N.jac_seg_pass[seg];
   wave_sync();
   constexpr int U = kJacUnroll, DT = U - 1, DR = 3;
   const rsrc_t bT = mkbuf(N.jac_stream), bF = mkbuf(N.jac_rowflag), bS = mkbuf(N.jac_slot), bP = mkbuf(Pv);
@@ -319,14 +340,14 @@ RG_DEV void dev_build_P(const DevNet &N, const double *__restrict__ rates, doubl
   uint64_t tw[U];
   double rk[U];
 #pragma unroll
-  for (int s = 0; s < DT; ++s) tw[s] = bload_u64(bT, l8, s * 512);
+  for (int s = 0; s < DT; ++s) tw[s] = bload_u64(bT, l8, (row0 + s) * 512);
 #pragma unroll
   for (int s = 0; s < DR; ++s) rk[s] = sload_f64(bK, (int)(tw[s] & 0xffff) * 8, 0);
-  uint64_t slot = bload_u64(bS, l8, 0), slot_nx = bload_u64(bS, l8, 512);
-  int pass = 0;
+  uint64_t slot = bload_u64(bS, l8, pass0 * 512), slot_nx = bload_u64(bS, l8, (pass0 + 1) * 512);
+  int pass = pass0;
   double sum = 0.0;
-  uint32_t fl = 0;
-  for (int r0 = 0; r0 < N.jac_rows; r0 += U) {
+  uint32_t fl = bload_u32(bF, l4, (row0 & ~63) * 4); // (a segment starts on a multiple of U rows, not of 64)
+  for (int r0 = row0; r0 < row1; r0 += U) {
     if ((r0 & 63) == 0) fl = bload_u32(bF, l4, r0 * 4); // "last row of its pass" flags of the next 64 rows, one per lane
 #pragma unroll
     for (int s = 0; s < U; ++s) {
@@ -376,11 +397,23 @@ RG_DEV void lds_sync() {
 #ifndef RG_CLAMP_LOADS
 #define RG_CLAMP_LOADS 1
 #endif
+//
+// Team mode (nteam > 1 waves of one workgroup on one cell, k_solve_team): wave 0 factors the columns k < ns as above while the
+// others wait; the trailing columns then go round by round, nteam groups of G columns per round, one group per wave.  What a
+// group needs from the columns k < ns and from the groups of earlier rounds (its LDS pivots and the dense pivots below the
+// round's first column) is independent of the round's other groups and runs in parallel, each wave on a work column of its own;
+// the rest of the round (the dense pivots that belong to the round's earlier groups, the group among itself, the stores) is
+// taken in turns between barriers.  Every column sees its pivots in the same order as with one wave: the factors are the same
+// to the last bit.  Every wave of the team executes the same number of barriers: 1 + (nteam + 1) * rounds.
+RG_DEV void team_barrier() { __syncthreads(); }
+
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
-                   double *__restrict__ Dinv, double *w, double *dl, int lane, long long *cyc = nullptr, double *dmy = nullptr) {
+                   double *__restrict__ Dinv, double *w, double *dl, int lane, long long *cyc = nullptr, double *dmy = nullptr,
+                   const int wv = 0, const int nteam = 1, volatile int *tfail = nullptr) {
   // dmy: 64 spare LDS doubles, one per lane (RG_BRANCHFREE)
-  // w: LDS work column;
-  // dl: LDS copy of D^-1 (the U columns are scaled by it, and a gather from LDS beats one from HBM)
+  // w: LDS work column (one per wave);
+  // dl: LDS copy of D^-1 (the U columns are scaled by it, and a gather from LDS beats one from HBM); shared by the team
+  // wv, nteam, tfail: this wave's place in the team, the team's size, the team's "zero pivot" flag (LDS, cleared by the caller)
   bool ok = true;
   long long c_scatter = 0, c_rect = 0, c_dense = 0, c_fin = 0, tq = 0;
 #define RG_TICK(acc) if (cyc) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - tq; tq = now_; }
@@ -403,13 +436,14 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   auto prefetch_col = [&]() {
 #if RG_CLAMP_LOADS
     const int op8 = min(l8, max(nxc.p1 - nxc.p0 - 1, 0) * 8); // (same clamp for the column's P entries)
-    nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = sload_f64(bP, op8, nxc.p0 * 8); nx_pr = bload_u16(bProw, op8 >> 2, nxc.p0 * 2);
+    nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = pload_f64(bP, op8, nxc.p0 * 8); nx_pr = bload_u16(bProw, op8 >> 2, nxc.p0 * 2);
 #else
-    nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = sload_f64(bP, l8, nxc.p0 * 8); nx_pr = bload_u16(bProw, l2, nxc.p0 * 2);
+    nx_dq = bload_u64(bUdesc, l8, nxc.d0 * 8); nx_pv = pload_f64(bP, l8, nxc.p0 * 8); nx_pr = bload_u16(bProw, l2, nxc.p0 * 2);
 #endif
     nx_fu = bload_u16(bUrow, l2, nxc.u0 * 2); nx_fl = bload_u16(bLrow, l2, nxc.lc0 * 2);
   };
   prefetch_col();
+  auto prime = [&](int widx) { nxc = load_col(widx); nx2 = load_col(widx + 1); prefetch_col(); }; // (team mode: a wave's groups are not consecutive work items)
   if (cyc) tq = (long long)__builtin_readcyclecounter();
 
   // ---- column j, part 1: scatter P(:,j) into the work column and apply the pivots k < ns through LDS -------------
@@ -428,7 +462,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     nxc = nx2; nx2 = load_col(widx + 2);
     prefetch_col();
     if (lane < cur.p1 - cur.p0) wv[pr] = pv;
-    for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[bload_u16(bProw, q * 2, 0)] = sload_f64(bP, q * 8, 0); // rare: > 64 entries
+    for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[bload_u16(bProw, q * 2, 0)] = pload_f64(bP, q * 8, 0); // rare: > 64 entries
     lds_sync();
     RG_TICK(c_scatter)
     constexpr int D = kLuDepth;
@@ -492,8 +526,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   // U part of the current column with rows < uend_rect: final after the LDS pivots; scaled and stored
   auto store_u = [&](double *wv, int uend) {
     int q = cur.u0 + lane;
-    if (q < uend) { const int k = cu_fu; sstore_f64(bU, l8, cur.u0 * 8, wv[k] * dl[k]); wv[k] = 0.0; }
-    for (q += 64; q < uend; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); sstore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
+    if (q < uend) { const int k = cu_fu; ustore_f64(bU, l8, cur.u0 * 8, wv[k] * dl[k]); wv[k] = 0.0; }
+    for (q += 64; q < uend; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); ustore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
   };
 
   // ---- column j, last part: pivot, scaled U and L columns to HBM, work column back to zero ------------------------
@@ -504,8 +538,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     const int ku = hasU ? (int)cu_fu : j, il = hasL ? (int)cu_fl : j;
     const double uv = wv[ku], dk = dl[ku], lv = wv[il];
     lds_order();
-    if (hasU) { sstore_f64(bU, l8, cur.u0 * 8, uv * dk); wv[ku] = 0.0; }
-    for (int q = cur.u0 + 64 + lane; q < cur.u1; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); sstore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
+    if (hasU) { ustore_f64(bU, l8, cur.u0 * 8, uv * dk); wv[ku] = 0.0; }
+    for (int q = cur.u0 + 64 + lane; q < cur.u1; q += 64) { const int k = bload_u16(bUrow, q * 2, 0); ustore_f64(bU, q * 8, 0, wv[k] * dl[k]); wv[k] = 0.0; }
     if (d == 0.0) ok = false;
     const double dinv = 1.0 / d;
     if (lane == 0) { Dinv[j] = dinv; dl[j] = dinv; wv[j] = 0.0; }
@@ -525,13 +559,13 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   };
 
   // ---- pivot-free columns, all at once: D^-1 = 1/P(j,j), L(:,j) = P(rows > j, j) * D^-1 --------------------------------
-  {
+  if (wv == 0) {
     const rsrc_t bLd = mkbuf(N.leaf_diag), bLe = mkbuf(N.leaf_ent);
     for (int q0 = 0; q0 < N.nleaf; q0 += 64) {
       const unsigned long long e = bload_u64(bLd, l8, q0 * 8);
       if (q0 + lane < N.nleaf) {
         const int jj = (int)(e >> 32);
-        const double d = sload_f64(bP, (int)(e & 0xfffff) * 8, 0);
+        const double d = pload_f64(bP, (int)(e & 0xfffff) * 8, 0);
         if (d == 0.0) ok = false;
         const double dinv = 1.0 / d;
         Dinv[jj] = dinv; dl[jj] = dinv;
@@ -541,14 +575,15 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     for (int q0 = 0; q0 < N.nleaf_ent; q0 += 64) {
       const unsigned long long e = bload_u64(bLe, l8, q0 * 8);
       if (q0 + lane < N.nleaf_ent)
-        sstore_f64(bL, (int)((e >> 20) & 0xfffff) * 8, 0, sload_f64(bP, (int)(e & 0xfffff) * 8, 0) * dl[(int)(e >> 40)]);
+        sstore_f64(bL, (int)((e >> 20) & 0xfffff) * 8, 0, pload_f64(bP, (int)(e & 0xfffff) * 8, 0) * dl[(int)(e >> 40)]);
     }
     wave_sync();
     RG_TICK(c_fin)
   }
 
-  for (int c = 0; c < N.nwork_sparse; ++c) { rect_phase(c, w); RG_TICK(c_dense) finish(cur.j, w); }
-  int j = ns;
+  if (wv == 0)
+    for (int c = 0; c < N.nwork_sparse; ++c) { rect_phase(c, w); RG_TICK(c_dense) finish(cur.j, w); }
+  if (nteam > 1) team_barrier(); // the columns k < ns and their D^-1 are in place for the whole team
 
   // ---- dense trailing block, G columns at a time (G = 12: every L column of the block is read n/12 times, not n times) ----
   // After a column's LDS pivots (k < ns) its entries in rows < ns are final and go straight to U; its tail rows
@@ -559,9 +594,43 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 #define RG_DENSE_G 12
 #endif
   constexpr int G = RG_DENSE_G;
-  for (; j < n; j += G) {
-    const int ng = min(G, n - j);
+  const int ngroups = (nt + G - 1) / G;
+#define RG_DENSE_LOAD(LA, LB, kb_, kend_)                                                                        \
+  _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
+    const int k = min((kb_) + u, max((kend_) - 1, ns)), kk = k - ns;                                              \
+    const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - k - 1) * 8; /* byte offset of L(0, k): L(row, k) sits row*8 further */ \
+    const double va = sload_f64(bL, rA8, cb), vb = sload_f64(bL, rB8, cb); /* unconditional: rows outside the column read neighbouring entries */ \
+    LA[u] = (rowA > k && rowA < n) ? va : 0.0;                                                                    \
+    LB[u] = (rowB > k && rowB < n) ? vb : 0.0;                                                                    \
+  }
+#define RG_DENSE_APPLY(LA, LB, kb_, kend_)                                                                       \
+  _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
+    const int k = (kb_) + u;                                                                                      \
+    if (k < (kend_)) {                                                                                            \
+      _Pragma("unroll") for (int c = 0; c < G; ++c) {                                                            \
+        const double t = bcast(wA[c], wB[c], k - ns);                                                             \
+        wA[c] -= LA[u] * t; wB[c] -= LB[u] * t;                                                                   \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+  // pivots kbeg <= k < kend of the block on the group's columns (kbeg - ns is a multiple of G, hence of 6)
+#define RG_DENSE_RANGE(kbeg_, kend_)                                                                             \
+  if ((kend_) > (kbeg_)) {                                                                                        \
+    double la0[3], lb0[3], la1[3], lb1[3];                                                                        \
+    RG_DENSE_LOAD(la0, lb0, (kbeg_), (kend_))                                                                     \
+    for (int kb = (kbeg_); kb < (kend_); kb += 6) {                                                               \
+      RG_DENSE_LOAD(la1, lb1, kb + 3, (kend_))                                                                    \
+      RG_DENSE_APPLY(la0, lb0, kb, (kend_))                                                                       \
+      RG_DENSE_LOAD(la0, lb0, kb + 6, (kend_))                                                                    \
+      RG_DENSE_APPLY(la1, lb1, kb + 3, (kend_))                                                                   \
+    }                                                                                                             \
+  }
+  for (int g0 = 0; g0 < ngroups; g0 += nteam) { // one round: groups g0 .. g0 + nteam - 1, this wave's is g0 + wv
+    const int j = ns + G * (g0 + wv), jround = ns + G * g0; // first column of the group / of the round
+    const bool active = g0 + wv < ngroups;
+    const int ng = active ? min(G, n - j) : 0;
     double wA[G], wB[G];
+    if (nteam > 1 && !(wv == 0 && g0 == 0)) { if (active) prime(N.nwork_sparse + (j - ns)); }
 #pragma unroll
     for (int c = 0; c < G; ++c) {
       wA[c] = 0.0; wB[c] = 0.0;
@@ -575,66 +644,55 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
         RG_TICK(c_fin)
       }
     }
-#define RG_DENSE_LOAD(LA, LB, kb_)                                                                               \
-  _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
-    const int k = min((kb_) + u, max(j - 1, ns)), kk = k - ns;                                                    \
-    const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - k - 1) * 8; /* byte offset of L(0, k): L(row, k) sits row*8 further */ \
-    const double va = sload_f64(bL, rA8, cb), vb = sload_f64(bL, rB8, cb); /* unconditional: rows outside the column read neighbouring entries */ \
-    LA[u] = (rowA > k && rowA < n) ? va : 0.0;                                                                    \
-    LB[u] = (rowB > k && rowB < n) ? vb : 0.0;                                                                    \
-  }
-#define RG_DENSE_APPLY(LA, LB, kb_)                                                                              \
-  _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
-    const int k = (kb_) + u;                                                                                      \
-    if (k < j) {                                                                                                  \
-      _Pragma("unroll") for (int c = 0; c < G; ++c) {                                                            \
-        const double t = bcast(wA[c], wB[c], k - ns);                                                             \
-        wA[c] -= LA[u] * t; wB[c] -= LB[u] * t;                                                                   \
-      }                                                                                                           \
-    }                                                                                                             \
-  }
-    if (j > ns) {
-      double la0[3], lb0[3], la1[3], lb1[3];
-      RG_DENSE_LOAD(la0, lb0, ns)
-      for (int kb = ns; kb < j; kb += 6) {
-        RG_DENSE_LOAD(la1, lb1, kb + 3)
-        RG_DENSE_APPLY(la0, lb0, kb)
-        RG_DENSE_LOAD(la0, lb0, kb + 6)
-        RG_DENSE_APPLY(la1, lb1, kb + 3)
-      }
+    if (nteam == 1) {
+      RG_DENSE_RANGE(ns, j)
+    } else {
+      if (active) { RG_DENSE_RANGE(ns, jround) } // the columns of earlier rounds: complete since the last barrier
     }
+    RG_TICK(c_dense)
+    for (int turn = 0; turn < nteam; ++turn) {
+      if (nteam > 1) team_barrier(); // the groups before this one in the round are complete
+      if (turn != wv || !active) continue;
+      if (nteam > 1) { RG_DENSE_RANGE(jround, j) }
+      RG_TICK(c_dense)
+      // the G columns of the group among themselves, and the stores (from registers)
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        if (c < ng) {
+          const int jc = j + c, kk = jc - ns;
+          const double d = bcast(wA[c], wB[c], kk);
+          if (d == 0.0) ok = false;
+          const double dinv = 1.0 / d;
+          if (lane == 0) { Dinv[jc] = dinv; dl[jc] = dinv; }
+          const double lA = (rowA > jc && rowA < n) ? wA[c] * dinv : 0.0, lB = (rowB > jc && rowB < n) ? wB[c] * dinv : 0.0;
+#pragma unroll
+          for (int c2 = c + 1; c2 < G; ++c2) {
+            if (c2 < ng) {
+              const double t = bcast(wA[c2], wB[c2], kk);
+              wA[c2] -= lA * t; wB[c2] -= lB * t;
+            }
+          }
+          lds_sync(); // dl[jc] is read below by the lanes of later columns
+          const int ub = ((nzus + kk * (kk - 1) / 2) - ns) * 8;                    // byte offset of U(0, jc): rows ns <= row < jc are stored
+          const int lb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - jc - 1) * 8; // byte offset of L(0, jc): rows > jc are stored
+          if (rowA < jc) ustore_f64(bU, rA8, ub, wA[c] * dl[rowA]);
+          else if (rowA > jc && rowA < n) sstore_f64(bL, rA8, lb, lA);
+          if (rowB < jc) ustore_f64(bU, rB8, ub, wB[c] * dl[rowB]);
+          else if (rowB > jc && rowB < n) sstore_f64(bL, rB8, lb, lB);
+        }
+      }
+      wave_sync(); // L, U, Dinv of these columns are read back from HBM by later columns
+      RG_TICK(c_fin)
+    }
+    if (nteam > 1) { // the round is complete (the next one reads its columns; after the last round wave 0 goes on alone)
+      if (!ok) *tfail = 1;
+      team_barrier();
+    }
+  }
+#undef RG_DENSE_RANGE
 #undef RG_DENSE_LOAD
 #undef RG_DENSE_APPLY
-    RG_TICK(c_dense)
-    // the G columns of the group among themselves, and the stores (from registers)
-#pragma unroll
-    for (int c = 0; c < G; ++c) {
-      if (c < ng) {
-        const int jc = j + c, kk = jc - ns;
-        const double d = bcast(wA[c], wB[c], kk);
-        if (d == 0.0) ok = false;
-        const double dinv = 1.0 / d;
-        if (lane == 0) { Dinv[jc] = dinv; dl[jc] = dinv; }
-        const double lA = (rowA > jc && rowA < n) ? wA[c] * dinv : 0.0, lB = (rowB > jc && rowB < n) ? wB[c] * dinv : 0.0;
-#pragma unroll
-        for (int c2 = c + 1; c2 < G; ++c2) {
-          if (c2 < ng) {
-            const double t = bcast(wA[c2], wB[c2], kk);
-            wA[c2] -= lA * t; wB[c2] -= lB * t;
-          }
-        }
-        lds_sync(); // dl[jc] is read below by the lanes of later columns
-        const int ub = ((nzus + kk * (kk - 1) / 2) - ns) * 8;                    // byte offset of U(0, jc): rows ns <= row < jc are stored
-        const int lb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - jc - 1) * 8; // byte offset of L(0, jc): rows > jc are stored
-        if (rowA < jc) sstore_f64(bU, rA8, ub, wA[c] * dl[rowA]);
-        else if (rowA > jc && rowA < n) sstore_f64(bL, rA8, lb, lA);
-        if (rowB < jc) sstore_f64(bU, rB8, ub, wB[c] * dl[rowB]);
-        else if (rowB > jc && rowB < n) sstore_f64(bL, rB8, lb, lB);
-      }
-    }
-    wave_sync(); // L, U, Dinv of these columns are read back from HBM by later columns
-    RG_TICK(c_fin)
-  }
+  if (nteam > 1) ok = *tfail == 0;
   if (cyc) { cyc[0] += c_scatter; cyc[1] += c_rect; cyc[2] += c_dense; cyc[3] += c_fin; }
 #undef RG_TICK
   return ok;
@@ -654,14 +712,14 @@ RG_DEV void dev_tri_sweep(const uint32_t *__restrict__ rc, const double *__restr
   const rsrc_t brc = mkbuf(rc), bval = mkbuf(val);
   const int l4 = lane * 4, l8 = lane * 8;
 #pragma unroll
-  for (int s = 0; s < D - 1; ++s) { r[s] = bload_u32(brc, l4, s * 256); v[s] = sload_f64(bval, l8, s * 512); }
+  for (int s = 0; s < D - 1; ++s) { r[s] = bload_u32(brc, l4, s * 256); v[s] = tload_f64(bval, l8, s * 512); }
   double x = 0.0;
   bool have = false; // x already holds this chunk's x[col] (read while the previous chunk of the same level was applied)
   for (int c = 0; c < nchunk; c += D) { // nchunk is a multiple of D (null chunks at the end)
 #pragma unroll
     for (int s = 0; s < D; ++s) {
       const int sl = (s + D - 1) % D; // the set applied one sub-step ago is free again
-      r[sl] = bload_u32(brc, l4, (c + s + D - 1) * 256); v[sl] = sload_f64(bval, l8, (c + s + D - 1) * 512);
+      r[sl] = bload_u32(brc, l4, (c + s + D - 1) * 256); v[sl] = tload_f64(bval, l8, (c + s + D - 1) * 512);
       const uint32_t wd = r[s], wn = r[(s + 1) % D];
       const int row = (int)(wd & 1023u), col = (int)((wd >> 10) & 1023u);
       const bool cont = (__builtin_amdgcn_readfirstlane((int)wd) >> 20) & 1;
@@ -713,7 +771,7 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
     const int kc_ = min((k_), n - 2); /* (not "k": the argument may mention the caller's k) */                     \
     const int kk = kc_ - ns;                                                                                       \
     const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - kc_ - 1) * 8; /* byte offset of L(0, k); rows k < row < n are stored */ \
-    la[S] = sload_f64(bL, rA8, cb); lb[S] = sload_f64(bL, rB8, cb); /* rows outside the column read neighbouring entries */ \
+    la[S] = tload_f64(bL, rA8, cb); lb[S] = tload_f64(bL, rB8, cb); /* rows outside the column read neighbouring entries */ \
   }
 #pragma unroll
     for (int s = 0; s < D; ++s) RG_DS_LOAD(s, ns + s)
@@ -739,7 +797,7 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
   {                                                                                                               \
     const int kk = max((k_), ns + 1) - ns;                                                                         \
     const int cb = ((nzus + kk * (kk - 1) / 2) - ns) * 8; /* byte offset of U(0, k); rows ns <= row < k are stored */ \
-    ua[S] = sload_f64(bU, rA8, cb); ub[S] = sload_f64(bU, rB8, cb);                                                \
+    ua[S] = tload_f64(bU, rA8, cb); ub[S] = tload_f64(bU, rB8, cb);                                                \
   }
 #pragma unroll
     for (int s = 0; s < D; ++s) RG_DS_LOAD(s, n - 1 - s)

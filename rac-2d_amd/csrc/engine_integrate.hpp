@@ -21,6 +21,7 @@ struct CellCtx {
   double *acor, *ewt;                                          // HBM, npad each: accumulated correction, inverse error weights (elementwise use only)
   double *yh, *Pv, *Lv, *Uv, *Dinv, *rates, *rtol, *atol;      // this cell's HBM slices
   int lane, n, npad;
+  int nteam;      // waves working on this cell (1, or 4 in k_solve_team: wave 0 holds this context, the others serve it)
   int *marker;    // developer aid: host-visible progress word, or null
 };
 
@@ -37,6 +38,10 @@ struct WaveConst {
 };
 enum { CYC_RHS = 0, CYC_JAC, CYC_LU, CYC_SOLVE, CYC_LU_PART };
 static __shared__ volatile WaveConst g_wc;
+// wave 0's requests to the other waves of its team (k_solve_team): written before a barrier, read after it
+enum { T_EXIT = 0, T_LU = 1, T_JAC = 2 };
+struct TeamCtl { int cmd, fail, cell, pad; double con; }; // cell: wave 0's current cell (its rate vector); con: -h*el0 of the Jacobian request
+static __shared__ volatile TeamCtl g_team;
 RG_DEV void cyc_add(int k, long long d) { g_wc.cyc[k] = g_wc.cyc[k] + d; }
 
 RG_DEV long long dev_clock() { return (long long)__builtin_readcyclecounter(); }
@@ -168,7 +173,17 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   if (!jok) {
     s.jcur = 1; s.nje++; s.nslj = s.nst; s.iplost = 0; s.conmin = fabs(con);
     dev_mark(c, 3000);
-    { const long long t0 = dev_clock(); dev_build_P<true>(N, c.rates, g_wc.nsite, c.y, con, true, c.Pv, c.lane); cyc_add(CYC_JAC, dev_clock() - t0); }
+    {
+      const long long t0 = dev_clock();
+      if (c.nteam > 1) { // every wave of the team builds the entries of its segment of the term stream
+        g_team.con = con; g_team.cmd = T_JAC; team_barrier();
+        dev_build_P<true>(N, c.rates, g_wc.nsite, c.y, con, true, c.Pv, c.lane, 0);
+        team_barrier();
+      } else {
+        dev_build_P<true>(N, c.rates, g_wc.nsite, c.y, con, true, c.Pv, c.lane);
+      }
+      cyc_add(CYC_JAC, dev_clock() - t0);
+    }
     dev_mark(c, 3001);
   }
   s.nlu++; s.con0 = con; s.ierpj = 0;
@@ -176,7 +191,8 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   {
     const long long t0 = dev_clock();
     long long part[4] = {0, 0, 0, 0};
-    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, part, c.wx + ((c.n + 1) & ~1))) s.ierpj = 1;
+    if (c.nteam > 1) { g_team.fail = 0; g_team.cmd = T_LU; team_barrier(); } // the helpers enter dev_lu with their own work columns
+    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, part, c.wx + ((c.n + 1) & ~1), 0, c.nteam, (volatile int *)&g_team.fail)) s.ierpj = 1;
     cyc_add(CYC_LU, dev_clock() - t0);
     for (int k = 0; k < 4; ++k) cyc_add(CYC_LU_PART + k, part[k]);
   }

@@ -68,6 +68,34 @@ def test_cost_hints_change_the_order_not_the_results(racgpu, setup):
     net.set_cost_hints(None)
 
 
+def test_four_waves_on_a_cell_give_the_bits_of_one(racgpu, setup):
+    """k_solve_team (racgpu_set_team_threshold): the costliest cells of a hinted pass are factored by four waves each; every
+    column of the LDU sees its pivots in the same order as with one wave, so abundances, times and counters are identical."""
+    net, y0 = setup
+    p = racgpu.default_params(); p.t_max = 3e2
+    cells = racgpu.cells.synth_batch(24, seed=5)
+    net.set_cost_hints(None)
+    base = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells), record=True)
+    assert net.last_team_cells() == 0
+    cost = base["stats"][:, racgpu.S_NST].astype(float)
+    try:
+        for frac, want in ((1e-9, 24), (1.5, None), (0.0, 0)):
+            net.set_team_threshold(frac)
+            net.set_cost_hints(cost)
+            out = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells), record=True)
+            nteam = net.last_team_cells()
+            if want is None:
+                assert 0 < nteam < 24, nteam  # some in teams, the rest one wave each, in the same pass
+            else:
+                assert nteam == want
+            for k in ("y", "t_final", "quality", "record", "touts"):
+                np.testing.assert_array_equal(out[k], base[k], err_msg="%s with team threshold %g" % (k, frac))
+            np.testing.assert_array_equal(out["stats"][:, :8], base["stats"][:, :8])
+    finally:
+        net.set_team_threshold(0.5)
+        net.set_cost_hints(None)
+
+
 def test_step_budget_stops_a_cell_like_a_premature_finish(racgpu, setup):
     net, y0 = setup
     p = racgpu.default_params(); p.max_steps_per_cell = 100
