@@ -204,10 +204,14 @@ int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
 int racgpu_set_cost_hints(racgpu_network *, const double *cost, int64_t ncell);
 /* With cost hints in place, a cell whose expected cost exceeds frac x (sum of the costs / wave slots of the GPU) -- a cell that
  * would take that share of the pass's ideal length all by itself -- is solved by a team of four waves (at most one team per CU),
- * started ahead of the rest.  Same arithmetic in the same order: results do not depend on it.  Default 0.5; frac <= 0: never. */
+ * started ahead of the rest.  Same arithmetic in the same order: results do not depend on it.  Default 0.5; frac <= 0: never.
+ * Independently of hints, the cells still being integrated when the queue is empty and at most one wave per CU is left are handed
+ * over to teams between two output times (frac < 0 switches that off as well). */
 int racgpu_set_team_threshold(racgpu_network *, double frac);
 /* cells the last solve pass gave to teams */
 int64_t racgpu_last_team_cells(const racgpu_network *);
+/* cells the last solve pass handed over to teams at its end (synchronises the handle's stream) */
+int64_t racgpu_last_parked_cells(racgpu_network *);
 /* bytes of device workspace racgpu_solve_batch keeps per cell (grows the handle's workspace on demand) */
 int64_t racgpu_workspace_bytes_per_cell(const racgpu_network *);
 /* HIP-event time of the last racgpu_solve_batch kernel on its stream, milliseconds (-1 if none) */

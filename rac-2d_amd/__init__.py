@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
     "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_rectify_abundances",
-    "racgpu_set_cost_hints", "racgpu_set_team_threshold", "racgpu_last_team_cells", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
+    "racgpu_set_cost_hints", "racgpu_set_team_threshold", "racgpu_last_team_cells", "racgpu_last_parked_cells", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
 ]
 
 
@@ -116,6 +116,8 @@ def lib():
     L.racgpu_set_team_threshold.argtypes = [vp, C.c_double]
     L.racgpu_last_team_cells.restype = C.c_int64
     L.racgpu_last_team_cells.argtypes = [vp]
+    L.racgpu_last_parked_cells.restype = C.c_int64
+    L.racgpu_last_parked_cells.argtypes = [vp]
     _lib = L
     return L
 
@@ -335,12 +337,17 @@ class Network:
 
     def set_team_threshold(self, frac):
         """With cost hints: cells expected to cost more than frac x (sum of costs / wave slots) are solved by four waves each
-        (racgpu_set_team_threshold; default 0.5, <= 0 never).  Results do not depend on it."""
+        (racgpu_set_team_threshold; default 0.5, <= 0 never; < 0 also switches off the hand-over of the last running cells to teams at
+        the end of a pass).  Results do not depend on it."""
         _check(lib().racgpu_set_team_threshold(self._h, float(frac)))
 
     def last_team_cells(self):
         """cells the last solve pass gave to four-wave teams"""
         return int(lib().racgpu_last_team_cells(self._h))
+
+    def last_parked_cells(self):
+        """cells the last solve pass handed over to teams at its end (between two output times, once the queue was empty)"""
+        return int(lib().racgpu_last_parked_cells(self._h))
 
     def last_kernel_ms(self):
         return lib().racgpu_last_kernel_ms(self._h)

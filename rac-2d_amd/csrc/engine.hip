@@ -112,33 +112,44 @@ struct SolveArgs {
   double *t_final; int *quality; long long *stats; double *record, *touts, *cell_out;
   const int *order;                 // queue order or null
   int slot0;                        // this launch's first workspace slot
+  int park_max;                     // k_solve: cells may be parked for a team once the queue is empty and <= park_max waves are left (0: never)
+  int *park_list, *park_count;      // slots holding parked cells, and how many
 };
+constexpr int kParkWords = 128;     // doubles reserved per slot for struct Parked (in front of the parked iterate)
+static_assert(sizeof(Parked) <= kParkWords * sizeof(double), "Parked outgrew its slot");
 
 // TEAM = 1: one wave per workgroup and per cell (k_solve, the bulk of a batch).  TEAM = 4 (k_solve_team): four waves per cell for
 // the few cells that would otherwise set the length of the pass on their own; wave 0 runs the integrator exactly as with TEAM =
 // 1, the others wait at a barrier for the parts that are shared out (the factorisation, dev_lu's team mode) -- same arithmetic
 // in the same order per column, same results to the last bit.
-template <int TEAM>
+template <int TEAM, bool RESUME>
 RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, const SolveArgs &A, double *lds) {
   const int lane = threadIdx.x & 63, wv = TEAM > 1 ? uniform_i((int)(threadIdx.x >> 6)) : 0;
-  const int slot = A.slot0 + blockIdx.x, n = N.nS, nlds = (n + 1) & ~1;
+  const int n = N.nS, nlds = (n + 1) & ~1;
   LdsViews v = carve(lds, nlds);
   CellCtx c;
   c.nteam = TEAM;
   c.y = v.y; c.savf = v.savf; c.wx = v.wx;
-  c.acor = W.acor + (size_t)slot * N.npad; c.ewt = W.ewt + (size_t)slot * N.npad;
-  c.rates = nullptr; c.yh = W.yh + (size_t)slot * 6 * N.npad; c.Pv = W.P + (size_t)slot * N.nnzJ;
-  c.Lv = W.L + (size_t)slot * N.nzl; c.Uv = W.U + (size_t)slot * N.nzu; c.Dinv = W.Dinv + (size_t)slot * N.npad;
-  c.rtol = W.rtol + (size_t)slot * N.npad; c.atol = W.atol + (size_t)slot * N.npad;
-  double *ygood = W.ygood + (size_t)slot * N.npad;
   c.lane = lane; c.n = n; c.npad = N.npad;
-  c.marker = slot == 0 ? W.marker : nullptr;
+  c.rates = nullptr; c.marker = nullptr;
+  double *ygood = nullptr;
+  auto bind = [&](int slot) { // the workspace slot the cell lives in (a resumed cell: the slot of the wave that parked it)
+    c.acor = W.acor + (size_t)slot * N.npad; c.ewt = W.ewt + (size_t)slot * N.npad;
+    c.yh = W.yh + (size_t)slot * 6 * N.npad; c.Pv = W.P + (size_t)slot * N.nnzJ;
+    c.Lv = W.L + (size_t)slot * N.nzl; c.Uv = W.U + (size_t)slot * N.nzu; c.Dinv = W.Dinv + (size_t)slot * N.npad;
+    c.rtol = W.rtol + (size_t)slot * N.npad; c.atol = W.atol + (size_t)slot * N.npad;
+    ygood = W.ygood + (size_t)slot * N.npad;
+  };
+  const int own_slot = A.slot0 + blockIdx.x;
+  bind(own_slot);
+  c.marker = own_slot == 0 ? W.marker : nullptr;
   if (TEAM > 1 && wv != 0) { // a helper wave: serve wave 0's requests until it has no more cells
     double *hw = lds + 3 * nlds + 64 + (wv - 1) * (nlds + 64); // work column + one spare double per lane
     for (;;) {
       team_barrier();
       const int cmd = g_team.cmd;
       if (cmd == T_EXIT) return;
+      if (RESUME) bind(g_team.slot);
       if (cmd == T_LU) dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, hw, c.y, lane, nullptr, hw + nlds, wv, TEAM, &g_team.fail);
       if (cmd == T_JAC) {
         dev_build_P<true>(N, W.rates + (size_t)g_team.cell * N.nR, g_wc.nsite, c.y, g_team.con, true, c.Pv, lane, wv);
@@ -147,18 +158,30 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
     }
   }
   g_wc.inv_neq = 1.0 / (double)(n + 1);
-  if (TEAM > 1 && lane == 0) atomicAdd(W.counter - 1, 1); // k_gate: this workgroup is resident (the team queue's counter is word [2], this is [1])
+  if (TEAM > 1 && !RESUME && lane == 0) atomicAdd(W.counter - 1, 1); // k_gate: this workgroup is resident (the team queue's counter is word [2], this is [1])
+  const int nparked = RESUME ? gptr(A.park_count)[0] : 0;
   for (;;) {
     int cell = 0;
     if (lane == 0) cell = atomicAdd(W.counter, 1);
     cell = uniform_i(cell);
     dev_mark(c, 10 + cell);
-    if (cell >= A.ncell) break;
-    if (A.order) cell = A.order[cell]; // longest-expected-first schedule (racgpu_set_cost_hints)
+    int slot = own_slot;
+    Parked *pk = nullptr;
+    if (RESUME) {
+      if (cell >= nparked) break;
+      slot = A.park_list[cell];
+      bind(slot);
+      g_team.slot = slot;
+      pk = reinterpret_cast<Parked *>(W.park + (size_t)slot * (N.npad + kParkWords));
+      cell = pk->cell;
+    } else {
+      if (cell >= A.ncell) break;
+      if (A.order) cell = A.order[cell]; // longest-expected-first schedule (racgpu_set_cost_hints)
+      if (W.park) pk = reinterpret_cast<Parked *>(W.park + (size_t)slot * (N.npad + kParkWords));
+    }
+    double *ypark = W.park ? W.park + (size_t)slot * (N.npad + kParkWords) + kParkWords : nullptr;
     const double *cp = A.cells + (size_t)cell * RACGPU_NPAR;
-    const long long cyc0 = dev_clock();
-    for (int k = 0; k < 8; ++k) g_wc.cyc[k] = 0;
-    g_wc.Tgas = cp[RACGPU_P_TGAS]; g_wc.nsite = cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES];
+    long long cyc0 = dev_clock();
     // The caller's per-cell time window (set_initial_condition_4solver / _continue, reference src/disk.f90:2075-2097,
     // 2128-2144): t_max of the cell, start time t0, first output step max(dt0, 1e-3 t0), and n_record recomputed from
     // them by chem_evol_solve_prepare_ongoing (src/chemistry.f90:1916-1938) for every cell and every local iteration.
@@ -167,30 +190,44 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
     const double dt_first = fmax(P.dt_first_step, t0 * 1e-3);
     const bool runnable = t_max > t0;
     const int n_record = runnable ? (int)ceil(log((t_max - t0) / dt_first * (P.ratio_tstep - 1.0) + 1.0) / log(P.ratio_tstep)) + 1 : 1;
-    dev_mark(c, 1);
-    { double rT, aT; dev_tolerances(N, P, A.tolj ? A.tolj[cell] : P.tol_j, cp[RACGPU_P_D2H], c.rtol, c.atol, rT, aT, lane); g_wc.rT = rT; g_wc.aT = aT; }
-    dev_mark(c, 2);
     c.rates = W.rates + (size_t)cell * N.nR; // filled by k_rates for the whole batch just before this launch
     if (TEAM > 1) g_team.cell = cell;
-    dev_mark(c, 3);
-    for (int i = lane; i < n; i += 64) c.y[i] = A.yio[(size_t)cell * n + i];
-    wave_sync();
-    if (A.flags & RACGPU_F_RECTIFY) { // rectify_abundances (src/chemistry.f90:2170-2201): E- takes up the net charge
-      double q = 0.0;
-      for (int i = lane; i < n; i += 64) q += c.y[i] * (double)gptr(N.s_charge)[i];
-      q = wave_sum(q);
-      if (lane == 0 && N.i_E >= 0) c.y[N.i_E] = c.y[N.i_E] + q;
+    if (!RESUME) {
+      for (int k = 0; k < 8; ++k) g_wc.cyc[k] = 0;
+      g_wc.Tgas = cp[RACGPU_P_TGAS]; g_wc.nsite = cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES];
+      dev_mark(c, 1);
+      { double rT, aT; dev_tolerances(N, P, A.tolj ? A.tolj[cell] : P.tol_j, cp[RACGPU_P_D2H], c.rtol, c.atol, rT, aT, lane); g_wc.rT = rT; g_wc.aT = aT; }
+      dev_mark(c, 2);
+      for (int i = lane; i < n; i += 64) c.y[i] = A.yio[(size_t)cell * n + i];
+      wave_sync();
+      if (A.flags & RACGPU_F_RECTIFY) { // rectify_abundances (src/chemistry.f90:2170-2201): E- takes up the net charge
+        double q = 0.0;
+        for (int i = lane; i < n; i += 64) q += c.y[i] * (double)gptr(N.s_charge)[i];
+        q = wave_sum(q);
+        if (lane == 0 && N.i_E >= 0) c.y[N.i_E] = c.y[N.i_E] + q;
+        wave_sync();
+      }
+    } else { // the per-cell constants, the counters and the iterate as the parking wave left them
+      const WaveConst &wc = pk->wc;
+      g_wc.nsite = wc.nsite; g_wc.Tgas = wc.Tgas; g_wc.rT = wc.rT; g_wc.aT = wc.aT;
+      for (int k = 0; k < 8; ++k) g_wc.cyc[k] = wc.cyc[k];
+      cyc0 -= pk->elapsed;
+      for (int i = lane; i < n; i += 64) c.y[i] = ypark[i];
       wave_sync();
     }
     double *rec = A.record ? A.record + (size_t)cell * P.n_record * (n + 1) : nullptr;
     double *tos = A.touts ? A.touts + (size_t)cell * P.n_record : nullptr;
     const int nrec = A.record || A.touts ? min(n_record, P.n_record) : n_record;
-    CellResult R = dev_evol_solve(N, P, c, t0, t_max, dt_first, nrec, rec, tos, ygood, cell == 0 ? W.trace : nullptr);
+    ParkIO io{};
+    io.rec = pk; io.resume = RESUME; io.counters = W.counter; io.ncell = A.ncell; io.nwaves = (int)gridDim.x;
+    io.park_max = (TEAM == 1 && pk) ? A.park_max : 0;
+    io.ypark = ypark; io.cell = cell; io.slot = slot; io.cyc0 = cyc0; io.park_list = A.park_list; io.park_count = A.park_count;
+    CellResult R = dev_evol_solve(N, P, c, t0, t_max, dt_first, nrec, rec, tos, ygood, cell == 0 ? W.trace : nullptr, io);
     dev_mark(c, 4);
     wave_sync();
     // hand-off (src/disk.f90:1716-1733): record(:, isav), touts(isav); with isav <= 1 ("No useful data produced") the
     // caller's abundances and t_final stay as they were
-    const bool useful = R.isav > 1;
+    const bool useful = R.isav > 1; // (a parked cell -- TEAM == 1 only -- writes nothing here: isav = 0, and the queue is empty)
     double nmol = 0.0;
     if (useful) {
       for (int i = lane; i < n; i += 64) {
@@ -200,7 +237,7 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
       }
       nmol = wave_sum(nmol) / cp[RACGPU_P_D2H];
     }
-    if (lane == 0) {
+    if (lane == 0 && !R.parked) {
       if (A.t_final) A.t_final[cell] = useful ? R.t_good : t0;
       if (A.quality) A.quality[cell] = R.quality;
       if (A.cell_out) {
@@ -221,18 +258,24 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
     dev_mark(c, 6);
   }
   dev_mark(c, 7);
+  if (TEAM == 1 && lane == 0) atomicAdd(W.counter + 3, 1); // one wave fewer (the parking rule counts them)
   if (TEAM > 1) { g_team.cmd = T_EXIT; team_barrier(); }
 }
 
 __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
   extern __shared__ double lds[];
-  solve_body<1>(*Np, *Pp, W, A, lds);
+  solve_body<1, false>(*Np, *Pp, W, A, lds);
 }
 
 constexpr int kTeam = 4;
 __global__ __launch_bounds__(64 * kTeam) void k_solve_team(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
   extern __shared__ double lds[];
-  solve_body<kTeam>(*Np, *Pp, W, A, lds);
+  solve_body<kTeam, false>(*Np, *Pp, W, A, lds);
+}
+// the cells k_solve parked, each taken up by a team in the workspace slot it was parked in
+__global__ __launch_bounds__(64 * kTeam) void k_solve_team_resume(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
+  extern __shared__ double lds[];
+  solve_body<kTeam, true>(*Np, *Pp, W, A, lds);
 }
 
 // Holds the stream that launches the bulk kernel until the team kernel's workgroups have started (or a bound of ~20 ms has passed:
@@ -309,8 +352,10 @@ struct racgpu_network {
   int *order_dev = nullptr; long order_cap = 0;
   std::vector<int> order_host;    // the queue order of the last hinted pass
   double team_frac = 0.5;         // racgpu_set_team_threshold
+  bool park_enabled = true;       // racgpu_set_team_threshold: frac < 0 also switches the hand-over at the end of a pass off
   hipStream_t team_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   long last_team_cells = 0;       // cells the last pass solved four waves at a time
+  int *parked_host = nullptr;     // pinned: cells the last pass (its last chunk) handed over to teams at its end
   bool timed = false;
   int cu_count = 0;
 
@@ -339,6 +384,7 @@ struct racgpu_network {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (team_stream) (void)hipStreamDestroy(team_stream);
+    if (parked_host) (void)hipHostFree(parked_host);
   }
 };
 
@@ -594,6 +640,8 @@ void racgpu_network::upload() {
   HIP_OK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   HIP_OK(hipStreamCreateWithFlags(&team_stream, hipStreamNonBlocking));
+  HIP_OK(hipHostMalloc((void **)&parked_host, sizeof(int)));
+  *parked_host = 0;
   { void *d = nullptr; HIP_OK(hipMalloc(&d, sizeof(DevNet))); HIP_OK(hipMemcpy(d, &dn, sizeof(DevNet), hipMemcpyHostToDevice)); dev_allocs.push_back(d); dn_dev = (DevNet *)d; }
   { void *d = nullptr; HIP_OK(hipMalloc(&d, sizeof(DevParams))); dev_allocs.push_back(d); dp_dev = (DevParams *)d; }
   uploaded = true;
@@ -615,10 +663,11 @@ void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   ws.ygood = alloc((size_t)slots * dn.npad);
   ws.acor = alloc((size_t)slots * dn.npad);
   ws.ewt = alloc((size_t)slots * dn.npad);
+  ws.park = alloc((size_t)slots * (dn.npad + kParkWords));
   void *c = nullptr;
-  HIP_OK(hipMalloc(&c, 64));
+  HIP_OK(hipMalloc(&c, 64 + (size_t)slots * sizeof(int)));
   ws_allocs.push_back(c);
-  ws.counter = (int *)c;
+  ws.counter = (int *)c; // 16 words of counters (solve_pass), then the list of slots that hold parked cells
   ws_slots = slots; ws_rate_cells = rate_cells;
 }
 
@@ -939,10 +988,17 @@ int racgpu_newton_solve(racgpu_network *h, const racgpu_params *p, const double 
 int racgpu_set_team_threshold(racgpu_network *h, double frac) {
   if (!h) return fail("null network");
   h->team_frac = frac;
+  h->park_enabled = frac >= 0.0;
   return 0;
 }
 
 int64_t racgpu_last_team_cells(const racgpu_network *h) { return h ? h->last_team_cells : -1; }
+
+int64_t racgpu_last_parked_cells(racgpu_network *h) {
+  if (!h || !h->parked_host) return -1;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+  return *h->parked_host;
+}
 
 int racgpu_set_cost_hints(racgpu_network *h, const double *cost, int64_t ncell) {
   if (!h) return fail("null network");
@@ -985,6 +1041,7 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
   const long team_cap = hinted && h->team_frac > 0.0 ? std::min<long>(h->cu_count, ncell) : 0; // at most one team per CU
   h->ensure_workspace(slots + team_cap, chunk_cells);
   h->last_team_cells = 0;
+  HIP_OK(hipMemsetAsync(h->parked_host, 0, sizeof(int), h->stream)); // (pinned host memory, in stream order)
   if (hinted) {
     if (h->order_cap < ncell) {
       HIP_OK(hipStreamSynchronize(h->stream));
@@ -1011,7 +1068,9 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
                        B.cell_out ? B.cell_out + (size_t)c0 * RACGPU_NOUT : nullptr);
     HIP_OK(hipGetLastError());
     // pass 2: the persistent integrator
-    HIP_OK(hipMemsetAsync(h->ws.counter, 0, 4 * sizeof(int), h->stream)); // [0] bulk queue, [1] team workgroups started, [2] team queue
+    // [0] k_solve's queue, [1] team workgroups started, [2] k_solve_team's queue, [3] k_solve waves that have left, [4] parked cells,
+    // [5] k_solve_team_resume's queue
+    HIP_OK(hipMemsetAsync(h->ws.counter, 0, 8 * sizeof(int), h->stream));
     if (c0 == 0 && first_timed) HIP_OK(hipEventRecord(h->ev0, h->stream));
     SolveArgs A{};
     A.ncell = (int)nc; A.flags = flags; A.cells = cells_c; A.yio = B.y + (size_t)c0 * nS;
@@ -1023,6 +1082,10 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
     A.cell_out = B.cell_out ? B.cell_out + (size_t)c0 * RACGPU_NOUT : nullptr;
     A.order = hinted ? h->order_dev + c0 : nullptr;
     A.slot0 = 0;
+    // Cells still being integrated once the queue is empty and at most one wave per CU is left are parked between two output
+    // times and taken up by teams (k_solve_team_resume): the end of a pass is a handful of cells on an otherwise idle chip.
+    const int park_max = h->park_enabled ? h->cu_count : 0;
+    A.park_max = park_max; A.park_list = h->ws.counter + 16; A.park_count = h->ws.counter + 4;
     // Cells that would take more than team_frac of the pass's ideal length on their own (sum of costs / wave slots) go to
     // k_solve_team, four waves each, on a second stream and ahead of the bulk kernel; they are the head of the sorted order.
     long nteamc = 0;
@@ -1053,6 +1116,14 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
       HIP_OK(hipGetLastError());
     }
     if (nteamc > 0) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    if (park_max > 0 && A.ncell > 0 && !std::getenv("RACGPU_NO_RESUME")) { // (developer aid: leave the parked cells where they are)
+      SolveArgs Rz = A;
+      DevWork Wr = h->ws;
+      Wr.counter = h->ws.counter + 5;
+      hipLaunchKernelGGL(k_solve_team_resume, dim3((unsigned)park_max), dim3(64 * kTeam), lds_bytes_team(h->dn), h->stream, h->dn_dev, h->dp_dev, Wr, Rz);
+      HIP_OK(hipGetLastError());
+      HIP_OK(hipMemcpyAsync(h->parked_host, h->ws.counter + 4, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
   }
 }
 

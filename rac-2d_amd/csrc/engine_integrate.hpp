@@ -40,7 +40,7 @@ enum { CYC_RHS = 0, CYC_JAC, CYC_LU, CYC_SOLVE, CYC_LU_PART };
 static __shared__ volatile WaveConst g_wc;
 // wave 0's requests to the other waves of its team (k_solve_team): written before a barrier, read after it
 enum { T_EXIT = 0, T_LU = 1, T_JAC = 2 };
-struct TeamCtl { int cmd, fail, cell, pad; double con; }; // cell: wave 0's current cell (its rate vector); con: -h*el0 of the Jacobian request
+struct TeamCtl { int cmd, fail, cell, slot; double con; }; // cell: wave 0's current cell (its rate vector); slot: its workspace slot; con: -h*el0 of the Jacobian request
 static __shared__ volatile TeamCtl g_team;
 RG_DEV void cyc_add(int k, long long d) { g_wc.cyc[k] = g_wc.cyc[k] + d; }
 
@@ -428,10 +428,52 @@ RG_DEV void dev_finish(const CellCtx &c, const Lsodes &s, double &t) { // label 
 }
 
 // One DLSODES call, ITASK = 4.  On entry y (LDS) is the user's Y; on exit it is Y at t.
-RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s, double &t, double tout, int &istate) {
+// The output loop's own scalars live in LDS and are read and written through a volatile view: between two DLSODES calls
+// they are touched a few times, while inside the call every register is wanted by the factorisation.
+struct EvolState {
+  double t, t_step, tout, t_good, rt_total, rt_last;
+  long long nst_acc, nfe_acc, nje_acc, nlu_acc;
+  int istate, nerr, nerr_c, qual, nrr, isav;
+};
+
+// A cell between two integrator steps, set aside by the wave that was solving it (k_solve once the queue is empty and few waves
+// are left) and taken up again by a team (k_solve_team_resume).  Everything else the integration needs -- Nordsieck array, P, L, U,
+// weights, tolerances, the hand-off record -- stays where it is, in the workspace slot of the wave that parked it.
+struct Parked {
+  int cell, i;           // the cell; the last output interval completed (the DLSODES call for interval i + 1 is under way)
+  int nst0, nfe0, nje0, nlu0; // the counters as that call found them
+  long long elapsed;     // shader-clock cycles spent on the cell so far
+  Lsodes s; EvolState e; WaveConst wc;
+};
+struct ParkIO {
+  Parked *rec;           // this slot's record (null: the cell can neither be parked nor resumed)
+  bool resume;           // take the cell up from *rec instead of starting it
+  const int *counters;   // [0] cells handed out, [3] waves that have left the kernel
+  int ncell, nwaves, park_max; // park_max > 0: park once every cell has been handed out and at most park_max waves are left
+  double *ypark;         // where the iterate of a parked cell goes (behind *rec)
+  int cell, slot; long long cyc0; // the cell, the workspace slot it lives in, the clock when it was started
+  int *park_list, *park_count;    // the list of slots holding parked cells
+};
+
+constexpr int kIstateParked = 99, kIstateResume = 98; // dev_lsodes_call: left between two steps / re-entered there
+
+RG_DEV bool dev_should_park(const ParkIO &io, int lane) {
+  int go = 0;
+  if (lane == 0) {
+    const int handed = __hip_atomic_load(io.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int left = __hip_atomic_load(io.counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    go = handed >= io.ncell && io.nwaves - left <= io.park_max;
+  }
+  return uniform_i(go) != 0;
+}
+
+RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s, double &t, double tout, int &istate, const ParkIO &io) {
   const double u = kUround;
   const int n = c.n, lane = c.lane, l8 = c.lane * 8;
   const rsrc_t bY = mkbuf(c.yh), bE = mkbuf(c.ewt);
+  const bool reentry = istate == kIstateResume; // a parked cell: straight back into the step loop
+  if (reentry) istate = 2;
+  if (!reentry) {
   if (istate != 1 && s.init == 0) { istate = -3; return; }
   if (istate == 1) { s.init = 0; if (tout == t) return; }
   if (istate == 3) {
@@ -505,7 +547,8 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
       if (istate == 2) s.jstart = -2;
     }
   }
-  bool first = (istate == 1);
+  }
+  bool first = !reentry && (istate == 1);
   for (;;) { // Block E
     if (!first) {
       if (s.nst - s.nslast >= s.mxstep) { istate = -1; dev_finish(c, s, t); return; }
@@ -559,50 +602,60 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
     if (fabs(s.tn - s.tcrit) <= 100.0 * u * hmx) { dev_finish(c, s, t); t = s.tcrit; istate = 2; return; }
     const double tnext = s.tn + s.h * (1.0 + 4.0 * u);
     if ((tnext - s.tcrit) * s.h > 0.0) { s.h = (s.tcrit - s.tn) * (1.0 - 4.0 * u); s.jstart = -2; }
+    if (io.park_max > 0 && dev_should_park(io, lane)) { istate = kIstateParked; return; } // between two steps: hand the cell over to a team?
   }
 }
 
 // chem_evol_solve for one cell.  y (LDS) in: abundances at t0; out: abundances at the end of the run.
 // ygood (HBM): the hand-off record, i.e. record(:, isav) of the caller's loop in calc_this_cell (reference
 // src/disk.f90:1716-1733): the last record whose T and H2 entries are not NaN.
-struct CellResult { double t_final, t_good; int quality, nerr, nrec_real, isav; long long nst, nfe, nje, nlu, qsum; int nfail; };
+struct CellResult { double t_final, t_good; int quality, nerr, nrec_real, isav; long long nst, nfe, nje, nlu, qsum; int nfail; bool parked; };
 
-// The output loop's own scalars live in LDS and are read and written through a volatile view: between two DLSODES calls
-// they are touched a few times, while inside the call every register is wanted by the factorisation.
-struct EvolState {
-  double t, t_step, tout, t_good, rt_total, rt_last;
-  long long nst_acc, nfe_acc, nje_acc, nlu_acc;
-  int istate, nerr, nerr_c, qual, nrr, isav;
-};
 
 RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const CellCtx &c, double t0, double t_max, double dt_first,
                                  int n_record, double *__restrict__ record, double *__restrict__ touts, double *__restrict__ ygood,
-                                 double *trace) {
+                                 double *trace, const ParkIO &io) {
   __shared__ Lsodes s_lds;
   __shared__ volatile EvolState e; // accessed by name: a reference would be a generic pointer (flat_load/flat_store)
   Lsodes &s = s_lds;
-  s = Lsodes{};
-  s.trace = trace; s.trace_cap = P.debug_max_calls;
-  s.tcrit = t_max; s.hmxi = (t_max > 0.0) ? 1.0 / t_max : 0.0; s.mxstep = P.mxstep > 0 ? P.mxstep : 500;
-  e.istate = 1; e.nerr = 0; e.nerr_c = 0; e.qual = 0; e.nrr = 1; e.isav = 1;
-  e.t = t0; e.t_step = dt_first; e.tout = t0 + dt_first; e.t_good = t0;
-  e.nst_acc = 0; e.nfe_acc = 0; e.nje_acc = 0; e.nlu_acc = 0;
-  // Deterministic stand-in for the reference's CPU-time guards (src/chemistry.f90:438, 480-491): the time the
-  // reference would have spent is MODELLED from the call counters with per-call costs (racgpu_params; defaults =
-  // the reference's measured costs on one core, SURVEY.md section 6: f 47 us, full Jacobian 10.4 ms, LU+solves
-  // ~1.0 ms per factorisation).
-  e.rt_total = 0.0; e.rt_last = 1e300;
   const int lane = c.lane, n = c.n, neq = c.n + 1;
-  if (touts) { if (lane == 0) touts[0] = t0; }
-  if (record) { for (int i = lane; i < n; i += 64) record[i] = c.y[i]; if (lane == 0) record[n] = g_wc.Tgas; }
-  for (int i = 2; i <= n_record; ++i) {
+  if (!io.resume) {
+    s = Lsodes{};
+    s.trace = trace; s.trace_cap = P.debug_max_calls;
+    s.tcrit = t_max; s.hmxi = (t_max > 0.0) ? 1.0 / t_max : 0.0; s.mxstep = P.mxstep > 0 ? P.mxstep : 500;
+    e.istate = 1; e.nerr = 0; e.nerr_c = 0; e.qual = 0; e.nrr = 1; e.isav = 1;
+    e.t = t0; e.t_step = dt_first; e.tout = t0 + dt_first; e.t_good = t0;
+    e.nst_acc = 0; e.nfe_acc = 0; e.nje_acc = 0; e.nlu_acc = 0;
+    // Deterministic stand-in for the reference's CPU-time guards (src/chemistry.f90:438, 480-491): the time the
+    // reference would have spent is MODELLED from the call counters with per-call costs (racgpu_params; defaults =
+    // the reference's measured costs on one core, SURVEY.md section 6: f 47 us, full Jacobian 10.4 ms, LU+solves
+    // ~1.0 ms per factorisation).
+    e.rt_total = 0.0; e.rt_last = 1e300;
+    if (touts) { if (lane == 0) touts[0] = t0; }
+    if (record) { for (int i = lane; i < n; i += 64) record[i] = c.y[i]; if (lane == 0) record[n] = g_wc.Tgas; }
+  } else {
+    s = io.rec->s;
+    s.trace = nullptr;
+    const EvolState &pe = io.rec->e;
+    e.t = pe.t; e.t_step = pe.t_step; e.tout = pe.tout; e.t_good = pe.t_good; e.rt_total = pe.rt_total; e.rt_last = pe.rt_last;
+    e.nst_acc = pe.nst_acc; e.nfe_acc = pe.nfe_acc; e.nje_acc = pe.nje_acc; e.nlu_acc = pe.nlu_acc;
+    e.istate = pe.istate; e.nerr = pe.nerr; e.nerr_c = pe.nerr_c; e.qual = pe.qual; e.nrr = pe.nrr; e.isav = pe.isav;
+  }
+  bool parked = false;
+  int park0[4] = {0, 0, 0, 0};
+  for (int i = io.resume ? io.rec->i + 1 : 2; i <= n_record; ++i) {
     double tout = e.tout;
     if (tout >= s.tcrit) tout = s.tcrit;
     int istate = e.istate;
     const bool restart = (istate == 1);
-    const int nst0 = restart ? 0 : s.nst, nfe0 = restart ? 0 : s.nfe, nje0 = restart ? 0 : s.nje, nlu0 = restart ? 0 : s.nlu;
+    int nst0 = restart ? 0 : s.nst, nfe0 = restart ? 0 : s.nfe, nje0 = restart ? 0 : s.nje, nlu0 = restart ? 0 : s.nlu;
+    if (io.resume && i == io.rec->i + 1) { // the call the cell was parked in
+      nst0 = io.rec->nst0; nfe0 = io.rec->nfe0; nje0 = io.rec->nje0; nlu0 = io.rec->nlu0;
+      istate = kIstateResume;
+    }
     double t = e.t;
-    dev_lsodes_call(N, P, c, s, t, tout, istate);
+    dev_lsodes_call(N, P, c, s, t, tout, istate, io);
+    if (istate == kIstateParked) { park0[0] = nst0; park0[1] = nfe0; park0[2] = nje0; park0[3] = nlu0; parked = true; break; }
     e.t = t;
     e.nst_acc = e.nst_acc + (s.nst - nst0); e.nfe_acc = e.nfe_acc + (s.nfe - nfe0); e.nje_acc = e.nje_acc + (s.nje - nje0); e.nlu_acc = e.nlu_acc + (s.nlu - nlu0);
     const double rt_this = P.rt_cost_f * (double)(s.nfe - nfe0) + P.rt_cost_jac * (double)(s.nje - nje0) + P.rt_cost_lu * (double)(s.nlu - nlu0);
@@ -652,6 +705,25 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     const double t_step = e.t_step * P.ratio_tstep;
     e.t_step = t_step;
     e.tout = t + t_step;
+  }
+  if (parked) { // the iterate, the integrator's scalars, the per-cell constants and counters; the slot goes on the list
+    for (int k = lane; k < n; k += 64) io.ypark[k] = c.y[k];
+    if (lane == 0) {
+      Parked *r = io.rec;
+      r->cell = io.cell; r->i = e.nrr; r->elapsed = dev_clock() - io.cyc0; r->s = s;
+      r->nst0 = park0[0]; r->nfe0 = park0[1]; r->nje0 = park0[2]; r->nlu0 = park0[3];
+      EvolState &pe = r->e;
+      pe.t = e.t; pe.t_step = e.t_step; pe.tout = e.tout; pe.t_good = e.t_good; pe.rt_total = e.rt_total; pe.rt_last = e.rt_last;
+      pe.nst_acc = e.nst_acc; pe.nfe_acc = e.nfe_acc; pe.nje_acc = e.nje_acc; pe.nlu_acc = e.nlu_acc;
+      pe.istate = e.istate; pe.nerr = e.nerr; pe.nerr_c = e.nerr_c; pe.qual = e.qual; pe.nrr = e.nrr; pe.isav = e.isav;
+      WaveConst &wc = r->wc;
+      wc.nsite = g_wc.nsite; wc.Tgas = g_wc.Tgas; wc.rT = g_wc.rT; wc.aT = g_wc.aT; wc.inv_neq = g_wc.inv_neq;
+      for (int k = 0; k < 8; ++k) wc.cyc[k] = g_wc.cyc[k];
+      io.park_list[atomicAdd(io.park_count, 1)] = io.slot;
+    }
+    CellResult R{};
+    R.parked = true;
+    return R;
   }
   const int nrr = e.nrr;
   const double t = e.t;

@@ -69,25 +69,30 @@ def test_cost_hints_change_the_order_not_the_results(racgpu, setup):
 
 
 def test_four_waves_on_a_cell_give_the_bits_of_one(racgpu, setup):
-    """k_solve_team (racgpu_set_team_threshold): the costliest cells of a hinted pass are factored by four waves each; every
-    column of the LDU sees its pivots in the same order as with one wave, so abundances, times and counters are identical."""
+    """k_solve_team (racgpu_set_team_threshold): the costliest cells of a hinted pass are factored by four waves each, and the
+    cells still running at the end of any pass are parked between two output times and taken up by teams
+    (k_solve_team_resume).  Every column of the LDU sees its pivots in the same order as with one wave, so abundances, times,
+    records and counters are identical whichever way a cell went."""
     net, y0 = setup
     p = racgpu.default_params(); p.t_max = 3e2
     cells = racgpu.cells.synth_batch(24, seed=5)
     net.set_cost_hints(None)
-    base = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells), record=True)
-    assert net.last_team_cells() == 0
-    cost = base["stats"][:, racgpu.S_NST].astype(float)
     try:
-        for frac, want in ((1e-9, 24), (1.5, None), (0.0, 0)):
+        net.set_team_threshold(-1.0)  # one wave per cell from start to end
+        base = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells), record=True)
+        assert net.last_team_cells() == 0 and net.last_parked_cells() == 0
+        cost = base["stats"][:, racgpu.S_NST].astype(float)
+        #        threshold, hints, cells in teams from the start, cells handed over (how many depends on who is quickest)
+        for frac, hinted, want_team, want_parked in ((0.5, False, 0, True), (1e-9, True, 24, False), (1.5, True, None, True), (0.0, True, 0, True)):
             net.set_team_threshold(frac)
-            net.set_cost_hints(cost)
+            net.set_cost_hints(cost if hinted else None)
             out = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells), record=True)
-            nteam = net.last_team_cells()
-            if want is None:
-                assert 0 < nteam < 24, nteam  # some in teams, the rest one wave each, in the same pass
+            nteam, nparked = net.last_team_cells(), net.last_parked_cells()
+            if want_team is None:
+                assert 0 < nteam < 24, nteam  # both ways in one pass
             else:
-                assert nteam == want
+                assert nteam == want_team, (frac, nteam)
+            assert (0 < nparked <= 24 - nteam) if want_parked else nparked == 0, (frac, nteam, nparked)
             for k in ("y", "t_final", "quality", "record", "touts"):
                 np.testing.assert_array_equal(out[k], base[k], err_msg="%s with team threshold %g" % (k, frac))
             np.testing.assert_array_equal(out["stats"][:, :8], base["stats"][:, :8])
