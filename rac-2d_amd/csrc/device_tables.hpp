@@ -64,9 +64,10 @@ struct DevNet {
   // triangular-solve schedules: one packed word per stored entry of the streamed part, row | col<<10 |
   // (next chunk continues this level)<<20; chunks of 64 entries hold one dependency level each; null: row == col
   const uint32_t *Lrc, *Urc;
-  // LU pivot descriptors, per column j one slice [d0, d1): for every pivot k < ns of the column, in U storage order,
-  // k | len<<16 | (1<<30 if the pivot opens a new level within column j) | start<<32, where [start, start+len) is
-  // (a piece of at most 64 rows of) L column k; slices are padded with null descriptors (len 0)
+  // LU pivot descriptors, per column j one slice [d0, d1): for every pivot k < ns of the column, in U storage order, one word
+  // for (a piece of at most 64 rows of) L column k, [start, start+len) in the storage: bits 0-15 k; 16-25 8*len; 30 "reload w[k]"
+  // (the pivot opens a new level within column j, or is the first of a fetch of 60); 32-52 2*start; 53-61 8*(len-1) (0 for
+  // len 0) -- everything the pivot loop needs as byte offsets.  Slices are padded with null descriptors (all zero).
   const unsigned long long *Udesc;
   const LuCol *lucol;        // [nwork+2] the LU's work list (engine.hip, upload): columns with pivots, then the trailing block
   int nwork_sparse, nwork;   // work items with j < ns / in all

@@ -593,12 +593,17 @@ void racgpu_network::upload() {
         c.u0 = S.Ucolptr[j]; c.u1 = S.Ucolend[j]; c.lc0 = S.Lcolptr[j]; c.lc1 = S.Lcolend[j]; c.p0 = S.Pcolptr[j]; c.p1 = S.Pcolptr[j + 1];
         c.ur = S.Ucolend[j]; // rows < ns only: the pivots ns..j-1 of a trailing column are applied in registers
         c.d0 = (int)ud.size(); c.j = j;
+        constexpr int kChunk = 64 / kLuDepth * kLuDepth; // descriptors the kernel fetches at a time: the first of a fetch reloads w[k] too
         for (int q = S.Ucolptr[j]; q < c.ur; ++q) {
           const int k = S.Urow[q];
           const int len = S.Lcolend[k] - S.Lcolptr[k];
-          for (int off = 0; off < std::max(len, 1); off += 64) // L columns longer than 64 rows: one descriptor per 64 rows
-            ud.push_back((unsigned long long)k | ((unsigned long long)std::min(64, len - off) << 16) |
-                         ((unsigned long long)((S.Ugrp[q] && off == 0) ? 1 : 0) << 30) | ((unsigned long long)(S.Lcolptr[k] + off) << 32));
+          for (int off = 0; off < std::max(len, 1); off += 64) { // L columns longer than 64 rows: one descriptor per 64 rows
+            const unsigned long long rows = (unsigned long long)std::min(64, len - off), start = (unsigned long long)(S.Lcolptr[k] + off);
+            const bool reload = (S.Ugrp[q] && off == 0) || ((int)ud.size() - c.d0) % kChunk == 0;
+            if (start >= (1ull << 20)) throw std::runtime_error("LU layout: L storage too large for the pivot descriptors");
+            ud.push_back((unsigned long long)k | ((rows * 8) << 16) | ((unsigned long long)(reload ? 1 : 0) << 30) |
+                         ((start * 2) << 32) | (((rows > 0 ? rows - 1 : 0) * 8) << 53));
+          }
         }
         while (ud.size() % kLuDepth) ud.push_back(0ull);
         c.d1 = (int)ud.size();

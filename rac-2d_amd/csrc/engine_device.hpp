@@ -448,7 +448,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 
   // ---- column j, part 1: scatter P(:,j) into the work column and apply the pivots k < ns through LDS -------------
   // Pivot k of column j does w[i] -= L(i,k) * w[k] over the rows i of L(:,k).  The pivots come as packed
-  // descriptors (k | len<<16 | newlevel<<30 | start<<32), 64 at a time, one per lane, sorted so that pivots which
+  // descriptors (device_tables.hpp, Udesc), 64 at a time, one per lane, sorted so that pivots which
   // do not feed each other (same level within the column, see build_symbolic) are adjacent: when a level opens,
   // ONE LDS read fetches w[k] for every lane's pivot, and the pivots of that level take their multiplier from the
   // owning lane (v_readlane) - no LDS round trip per pivot.  The updates are LDS atomics (ds_add_f64, no return),
@@ -472,27 +472,21 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
       const unsigned long long dq = (base == cur.d0) ? dq0 : bload_u64(bUdesc, l8, base * 8);
       const int dlo = (int)(dq & 0xffffffffull), dhi = (int)(dq >> 32);
       const int myk = dlo & 0xffff;
-      const unsigned long long opens = __ballot((((dlo >> 30) & 1) != 0 || lane == 0) && lane < nk);
       double tvv = 0.0;
-      int a[D], z[D];
+      int ds[D]; // low word of the descriptor in each register set (wave-uniform)
       uint16_t i[D];
       double l[D];
+      // lanes past the end of the L column re-read its LAST entry instead of whatever follows it: a 512-byte wave load of a column
+      // of 8 entries then touches one cache line instead of eight (the pivot loop alone fetched 2.6x its useful bytes before).
+      // The lane index of the prefetch may run past the chunk (v_readlane takes it modulo 64): whatever descriptor sits there
+      // names a valid piece of L, and what is loaded for it is never applied.
 #define RG_LU_ISSUE(S, tt)                                                                                        \
   {                                                                                                               \
-    const int tq_ = min((tt), nk - 1);                                                                             \
-    a[S] = __builtin_amdgcn_readlane(dhi, tq_);                                                                    \
-    z[S] = (__builtin_amdgcn_readlane(dlo, tq_) >> 16) & 0x3fff; /* rows in this piece of the L column (<= 64) */  \
-    RG_LU_LOADS(S)                                                                                                 \
+    const int hi_ = __builtin_amdgcn_readlane(dhi, (tt));                                                          \
+    ds[S] = __builtin_amdgcn_readlane(dlo, (tt));                                                                  \
+    const int a2_ = hi_ & 0x1fffff, o8_ = min(l8, (int)((unsigned)hi_ >> 21));                                     \
+    i[S] = bload_u16(bLrow, o8_ >> 2, a2_); l[S] = sload_f64(bL, o8_, a2_ << 2);                                   \
   }
-#if RG_CLAMP_LOADS
-  // lanes past the end of the L column re-read its LAST entry instead of whatever follows it: a 512-byte wave load of a column
-  // of 8 entries then touches one cache line instead of eight (the pivot loop alone fetched 2.6x its useful bytes before)
-#define RG_LU_LOADS(S)                                                                                            \
-    { const int o8_ = min(l8, max(z[S] - 1, 0) * 8);                                                               \
-      i[S] = bload_u16(bLrow, o8_ >> 2, a[S] * 2); l[S] = sload_f64(bL, o8_, a[S] * 8); }
-#else
-#define RG_LU_LOADS(S) { i[S] = bload_u16(bLrow, l2, a[S] * 2); l[S] = sload_f64(bL, l8, a[S] * 8); }
-#endif
 #pragma unroll
       for (int s = 0; s < D - 1; ++s) { RG_LU_ISSUE(s, s) __builtin_amdgcn_sched_barrier(0); } // keep the issue order: data returns in order
       for (int t = 0; t < nk; t += D) {
@@ -500,7 +494,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
         for (int s = 0; s < D; ++s) {
           RG_LU_ISSUE((s + D - 1) % D, t + s + D - 1)
           const int tt = t + s;
-          if ((opens >> tt) & 1ull) { // w[k] of this level's pivots is final now
+          if (ds[s] & (1 << 30)) { // w[k] of this level's pivots is final now
             lds_order();
             tvv = wv[myk];
             asm volatile("" : "+v"(tvv)); // take the LDS wait here, so that pivots which do not open a level never wait on LDS
@@ -509,16 +503,11 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
           src.d = tvv;
           tv.w[0] = __builtin_amdgcn_readlane(src.w[0], tt);
           tv.w[1] = __builtin_amdgcn_readlane(src.w[1], tt);
-#if RG_BRANCHFREE
           // no exec-masked branch: lanes past the end of the L column add (a finite product of neighbouring entries) to a slot of their own
-          atomicAdd(lane < z[s] ? &wv[i[s]] : &dmy[lane], -(l[s] * tv.d));
-#else
-          if (lane < z[s]) atomicAdd(&wv[i[s]], -(l[s] * tv.d)); // (program order of LDS accesses is kept by the compiler: may-alias)
-#endif
+          atomicAdd(l8 < ((ds[s] >> 16) & 0x3ff) ? &wv[i[s]] : &dmy[lane], -(l[s] * tv.d));
         }
       }
 #undef RG_LU_ISSUE
-#undef RG_LU_LOADS
     }
     RG_TICK(c_rect)
   };

@@ -15,6 +15,17 @@ def run(cells, tag):
     print("%-34s %.2f s  kernel %.0f ms  team cells %d  total steps %d" % (tag, t1 - t0, net.last_kernel_ms(), net.last_team_cells(), out["stats"][:, 0].sum()))
     return out
 
+SHORT = len(sys.argv) > 1
+if SHORT:
+    idx = [8262, 1054, 9248, 6485]
+    cells = allc[idx]
+    for frac in (-1.0, 1e-9):
+        net.set_team_threshold(frac); net.set_cost_hints(np.ones(len(idx)))
+        o3 = run(cells, "costliest alone, team frac %g" % frac)
+        st = o3["stats"]
+        for k, i in enumerate(idx):
+            print("cell %5d: cyc=%.2fe9 | per LU %.2fM (scatter %.2f rect %.2f dense %.2f fin %.2f)" % (i, st[k, 8] / 1e9, st[k, 11] / st[k, 3] / 1e6, st[k, 13] / st[k, 3] / 1e6, st[k, 14] / st[k, 3] / 1e6, st[k, 15] / st[k, 3] / 1e6, (st[k, 11] - st[k, 13] - st[k, 14] - st[k, 15]) / st[k, 3] / 1e6))
+    sys.exit(0)
 net.set_team_threshold(-1.0)
 out = run(allc, "full batch, queue order, no teams")
 net.set_team_threshold(0.5)
@@ -34,6 +45,7 @@ for frac in (0.0, 1e-9):
     o3 = run(cells, "8 costliest alone, team frac %g" % frac)
 st = o3["stats"]
 for k, i in enumerate(idx):
-    print("cell %5d: NST=%d NLU=%d cyc=%.2fe9 (%.2f s) | rhs %.3f jac %.3f lu %.3f solve %.3f | per LU %.2fM per jac %.2fM per solve %.3fM per f %.3fM" % (
+    print("cell %5d: NST=%d NLU=%d cyc=%.2fe9 (%.2f s) | rhs %.3f jac %.3f lu %.3f solve %.3f | per LU %.2fM (scatter %.2f rect %.2f dense %.2f fin %.2f) per jac %.2fM per solve %.3fM per f %.3fM" % (
         i, st[k, 0], st[k, 3], st[k, 8] / 1e9, st[k, 8] / 2.4e9, *[st[k, c] / st[k, 8] for c in (9, 10, 11, 12)], st[k, 11] / max(st[k, 3], 1) / 1e6,
+        st[k, 13] / max(st[k, 3], 1) / 1e6, st[k, 14] / max(st[k, 3], 1) / 1e6, st[k, 15] / max(st[k, 3], 1) / 1e6, (st[k, 11] - st[k, 13] - st[k, 14] - st[k, 15]) / max(st[k, 3], 1) / 1e6,
         st[k, 10] / max(st[k, 2], 1) / 1e6, st[k, 12] / max(st[k, 1], 1) / 1e6, st[k, 9] / max(st[k, 1], 1) / 1e6))
