@@ -584,8 +584,12 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 #endif
   constexpr int G = RG_DENSE_G;
   const int ngroups = (nt + G - 1) / G;
+#ifndef RG_DENSE_AHEAD
+#define RG_DENSE_AHEAD 2 // L columns of the block per register set (two sets: one being applied, one in flight)
+#endif
+  static_assert(RG_DENSE_G % (2 * RG_DENSE_AHEAD) == 0, "a group's first column must start a pair of register sets");
 #define RG_DENSE_LOAD(LA, LB, kb_, kend_)                                                                        \
-  _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
+  _Pragma("unroll") for (int u = 0; u < RG_DENSE_AHEAD; ++u) {                                                                \
     const int k = min((kb_) + u, max((kend_) - 1, ns)), kk = k - ns;                                              \
     const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - k - 1) * 8; /* byte offset of L(0, k): L(row, k) sits row*8 further */ \
     const double va = sload_f64(bL, rA8, cb), vb = sload_f64(bL, rB8, cb); /* unconditional: rows outside the column read neighbouring entries */ \
@@ -593,7 +597,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     LB[u] = (rowB > k && rowB < n) ? vb : 0.0;                                                                    \
   }
 #define RG_DENSE_APPLY(LA, LB, kb_, kend_)                                                                       \
-  _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                                \
+  _Pragma("unroll") for (int u = 0; u < RG_DENSE_AHEAD; ++u) {                                                                \
     const int k = (kb_) + u;                                                                                      \
     if (k < (kend_)) {                                                                                            \
       _Pragma("unroll") for (int c = 0; c < G; ++c) {                                                            \
@@ -602,16 +606,16 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
       }                                                                                                           \
     }                                                                                                             \
   }
-  // pivots kbeg <= k < kend of the block on the group's columns (kbeg - ns is a multiple of G, hence of 6)
+  // pivots kbeg <= k < kend of the block on the group's columns (kbeg - ns is a multiple of G, hence of 2 * RG_DENSE_AHEAD)
 #define RG_DENSE_RANGE(kbeg_, kend_)                                                                             \
   if ((kend_) > (kbeg_)) {                                                                                        \
-    double la0[3], lb0[3], la1[3], lb1[3];                                                                        \
+    double la0[RG_DENSE_AHEAD], lb0[RG_DENSE_AHEAD], la1[RG_DENSE_AHEAD], lb1[RG_DENSE_AHEAD];                                                                        \
     RG_DENSE_LOAD(la0, lb0, (kbeg_), (kend_))                                                                     \
-    for (int kb = (kbeg_); kb < (kend_); kb += 6) {                                                               \
-      RG_DENSE_LOAD(la1, lb1, kb + 3, (kend_))                                                                    \
+    for (int kb = (kbeg_); kb < (kend_); kb += 2 * RG_DENSE_AHEAD) {                                                               \
+      RG_DENSE_LOAD(la1, lb1, kb + RG_DENSE_AHEAD, (kend_))                                                                    \
       RG_DENSE_APPLY(la0, lb0, kb, (kend_))                                                                       \
-      RG_DENSE_LOAD(la0, lb0, kb + 6, (kend_))                                                                    \
-      RG_DENSE_APPLY(la1, lb1, kb + 3, (kend_))                                                                   \
+      RG_DENSE_LOAD(la0, lb0, kb + 2 * RG_DENSE_AHEAD, (kend_))                                                                    \
+      RG_DENSE_APPLY(la1, lb1, kb + RG_DENSE_AHEAD, (kend_))                                                                   \
     }                                                                                                             \
   }
   for (int g0 = 0; g0 < ngroups; g0 += nteam) { // one round: groups g0 .. g0 + nteam - 1, this wave's is g0 + wv
@@ -741,37 +745,54 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
   const bool hasA = rowA < n, hasB = rowB < n;
   const rsrc_t bL = mkbuf(Lv), bU = mkbuf(Uv);
   double xA = hasA ? w[rowA] : 0.0, xB = hasB ? w[rowB] : 0.0;
-  auto bcast = [&](int kk) -> double { // x of trailing row ns + kk
-    union { double d; int i[2]; } s, t;
-    s.d = (kk < 64) ? xA : xB;
-    const int src = (kk < 64) ? kk : kk - 64;
-    t.i[0] = __builtin_amdgcn_readlane(s.i[0], src);
-    t.i[1] = __builtin_amdgcn_readlane(s.i[1], src);
-    return t.d;
-  };
-  // the trailing columns are stored back to back in index order, so their starts have closed forms (scalar ALU)
+  // The trailing columns are stored back to back in index order: the start of column k+1 follows from that of column k by one
+  // scalar add.  Lane l holds rows ns + l ("A") and ns + 64 + l ("B").  A column of L among the first 64 of the block touches
+  // the A rows below its diagonal (select) and every B row (no select); a later one touches B rows only: nothing is loaded or
+  // computed for A.  U mirrors that.  Lanes whose row lies outside the matrix carry garbage that is never read (the broadcasts
+  // take rows < n only).  The loops run to a multiple of the depth: columns past the end are switched off by the same selects
+  // (the clamped multiplier is finite, and the values loaded for a column past the end meet only switched-off or unused lanes);
+  // their loads stay inside the slot's storage or the spare behind it.
   const int nzls = N.nzl_stream, nzus = N.nzu_stream;
   constexpr int D = RG_DS_DEPTH;
+  static_assert(64 % D == 0, "the first 64 columns of the block are taken in whole groups of D");
+  auto rl = [&](double v, int src) -> double { // v of lane src
+    union { double d; int i[2]; } s_, t_;
+    s_.d = v;
+    t_.i[0] = __builtin_amdgcn_readlane(s_.i[0], src);
+    t_.i[1] = __builtin_amdgcn_readlane(s_.i[1], src);
+    return t_.d;
+  };
   if (nt > 1) {
-    // forward: columns k = ns .. n-2 of L, rows k+1 .. n-1
+    // forward: columns k = ns .. n-2 of L, rows k+1 .. n-1; byte offset of L(0, k): ((nzls + kk (nt-1) - kk (kk-1)/2) - k - 1) * 8
     double la[D], lb[D];
-#define RG_DS_LOAD(S, k_)                                                                                          \
+    int cb = (nzls - ns - 1) * 8, str = (nt - 2) * 8; // of the next column to load, and the step to the one after it
+#define RG_DS_LOAD(S, WITH_A)                                                                                      \
   {                                                                                                               \
-    const int kc_ = min((k_), n - 2); /* (not "k": the argument may mention the caller's k) */                     \
-    const int kk = kc_ - ns;                                                                                       \
-    const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - kc_ - 1) * 8; /* byte offset of L(0, k); rows k < row < n are stored */ \
-    la[S] = tload_f64(bL, rA8, cb); lb[S] = tload_f64(bL, rB8, cb); /* rows outside the column read neighbouring entries */ \
+    if (WITH_A) la[S] = tload_f64(bL, rA8, cb);                                                                    \
+    lb[S] = tload_f64(bL, rB8, cb);                                                                                \
+    cb += str; str -= 8;                                                                                           \
   }
 #pragma unroll
-    for (int s = 0; s < D; ++s) RG_DS_LOAD(s, ns + s)
-    for (int k0 = ns; k0 < n - 1; k0 += D) {
+    for (int s = 0; s < D; ++s) RG_DS_LOAD(s, true)
+    const int kend = nt - 1, kmid = min(64, kend);
+    int k0 = 0;
+    for (; k0 < kmid; k0 += D) { // columns among the first 64: A below the diagonal, all of B
 #pragma unroll
       for (int s = 0; s < D; ++s) {
-        const int k = k0 + s; // k > n-2: nothing left below the diagonal, the selects below switch every lane off
-        const double t = bcast(min(k - ns, nt - 1));
-        xA -= ((rowA > k && hasA) ? la[s] : 0.0) * t;
-        xB -= ((rowB > k && hasB) ? lb[s] : 0.0) * t;
-        RG_DS_LOAD(s, k + D)
+        const int kk = k0 + s;
+        const double t = rl(xA, min(kk, nt - 1));
+        xA -= ((lane > kk) ? la[s] : 0.0) * t;
+        xB -= lb[s] * t;
+        RG_DS_LOAD(s, true)
+      }
+    }
+    for (; k0 < kend; k0 += D) { // later columns: B below the diagonal, nothing of A
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const int kk = k0 + s;
+        const double t = rl(xB, min(kk, nt - 1) - 64);
+        xB -= ((lane > kk - 64) ? lb[s] : 0.0) * t;
+        RG_DS_LOAD(s, false)
       }
     }
 #undef RG_DS_LOAD
@@ -780,24 +801,51 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
   if (hasA) xA = xA * Dinv[rowA];
   if (hasB) xB = xB * Dinv[rowB];
   if (nt > 1) {
-    // backward: columns k = n-1 .. ns+1 of U, rows ns .. k-1
+    // backward: columns k = n-1 .. ns+1 of U, rows ns .. k-1; byte offset of U(0, k): ((nzus + kk (kk-1)/2) - ns) * 8.
+    // Columns kk >= 64: all of A, B above the diagonal; in whole groups of D while they last, the rest one by one.
     double ua[D], ub[D];
-#define RG_DS_LOAD(S, k_)                                                                                          \
+    int kk = nt - 1;
+    int cb = ((nzus + kk * (kk - 1) / 2) - ns) * 8, str = -(kk - 1) * 8; // of the next column to load, and the step down from it
+#define RG_DS_LOAD(S, WITH_B)                                                                                      \
   {                                                                                                               \
-    const int kk = max((k_), ns + 1) - ns;                                                                         \
-    const int cb = ((nzus + kk * (kk - 1) / 2) - ns) * 8; /* byte offset of U(0, k); rows ns <= row < k are stored */ \
-    ua[S] = tload_f64(bU, rA8, cb); ub[S] = tload_f64(bU, rB8, cb);                                                \
+    ua[S] = tload_f64(bU, rA8, cb);                                                                                \
+    if (WITH_B) ub[S] = tload_f64(bU, rB8, cb);                                                                    \
+    cb += str; str += 8;                                                                                           \
   }
+    if (kk - (D - 1) >= 64) {
 #pragma unroll
-    for (int s = 0; s < D; ++s) RG_DS_LOAD(s, n - 1 - s)
-    for (int k0 = n - 1; k0 > ns; k0 -= D) {
+      for (int s = 0; s < D; ++s) RG_DS_LOAD(s, true)
+      for (; kk - (D - 1) >= 64; kk -= D) {
 #pragma unroll
-      for (int s = 0; s < D; ++s) {
-        const int k = k0 - s; // k <= ns: no rows of the block above the diagonal, every lane is switched off
-        const double t = bcast(max(k - ns, 0));
-        xA -= ((rowA < k && hasA) ? ua[s] : 0.0) * t;
-        xB -= ((rowB < k && hasB) ? ub[s] : 0.0) * t;
-        RG_DS_LOAD(s, k - D)
+        for (int s = 0; s < D; ++s) {
+          const int k1 = kk - s;
+          const double t = rl(xB, k1 - 64);
+          xA -= ua[s] * t;
+          xB -= ((lane < k1 - 64) ? ub[s] : 0.0) * t;
+          RG_DS_LOAD(s, true) // (runs up to D columns past the last group: loaded, not applied)
+        }
+      }
+      cb = ((nzus + kk * (kk - 1) / 2) - ns) * 8; str = -(kk - 1) * 8;
+    }
+    for (; kk >= 64; --kk) { // at most D - 1 columns
+      const double t = rl(xB, kk - 64);
+      const double va = tload_f64(bU, rA8, cb), vb = tload_f64(bU, rB8, cb);
+      cb += str; str += 8;
+      xA -= va * t;
+      xB -= ((lane < kk - 64) ? vb : 0.0) * t;
+    }
+    // columns kk < 64: A above the diagonal, nothing of B; kk <= 0 (the loop runs to a multiple of D): no rows, every lane off
+    if (kk > 0) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) RG_DS_LOAD(s, false)
+      for (; kk > 0; kk -= D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          const int k1 = kk - s;
+          const double t = rl(xA, max(k1, 0));
+          xA -= ((lane < k1) ? ua[s] : 0.0) * t;
+          RG_DS_LOAD(s, false)
+        }
       }
     }
 #undef RG_DS_LOAD
