@@ -271,6 +271,7 @@ def main():
     net.set_stream(stream.cuda_stream)
 
     kernel_ms = []
+    teams = [0, 0]  # cells of the last pass solved by four-wave teams from the start / handed over to teams at the end of the pass
 
     def one_pass():
         y_d.copy_(yinit_d)
@@ -291,6 +292,7 @@ def main():
                 dist.all_gather_into_tensor(gathered, block_d)  # the path's single exchange: RCCL over xGMI
         torch.cuda.synchronize(dev)
         kernel_ms.append(net.last_kernel_ms())
+        teams[0], teams[1] = net.last_team_cells(), net.last_parked_cells()
         if not args.no_hints:
             # cost feedback, as between two global iterations of the disk model: the cycles each cell took in this pass
             # order the next pass (costliest first).  Part of the pass, so it is inside the timed region.
@@ -353,13 +355,19 @@ def main():
             "config": {"workload": wl, "cells_per_gpu": ncell,
                        "parallelism": "cells sharded over %d GPU(s) (%s), one RCCL all-gather of abundances + t_final + quality + counters at output" % (world, args.scaling),
                        "local_iterations": args.nlocal_iter,
+                       # cells the last pass gave to four-wave teams: from the start (cost hints; racgpu_set_team_threshold) / between
+                       # two integrator steps once the queue was empty and at most one wave per CU was left
+                       "cells_in_teams": {"from_start": teams[0], "handed_over": teams[1]},
                        "scheduling": ("costliest-first from the previous pass's per-cell cycle counts (racgpu_set_cost_hints)" if hinted
                                       else "queue order (no previous pass to take cost hints from)"),
                        # rank 0's first warm-up pass runs in queue order: its rate is the no-feedback figure
                        "queue_order_first_pass": ({"ms": 1e3 * first_pass_s, "cell_steps_per_s_rank0": float(stats[:, 0].sum()) / first_pass_s}
                                                   if (first_pass_s and hinted) else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_solve", "kernel_ms": kms,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         # one pass = k_solve (one wave per cell) followed by k_solve_team_resume (the cells handed over at its end),
+                         # with k_solve_team (cells in teams from the start) alongside: timed as a whole between two HIP events
+                         "kernel": "k_solve (+ k_solve_team, k_solve_team_resume)", "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_cell_step": abytes / max(nst, 1.0)},
             "cell_steps_per_pass_rank0": nst, "mean_steps_per_cell": nst / ncell,

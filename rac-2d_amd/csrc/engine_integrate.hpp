@@ -192,7 +192,10 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
     const long long t0 = dev_clock();
     long long part[4] = {0, 0, 0, 0};
     if (c.nteam > 1) { g_team.fail = 0; g_team.cmd = T_LU; team_barrier(); } // the helpers enter dev_lu with their own work columns
-    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, part, c.wx + ((c.n + 1) & ~1), 0, c.nteam, (volatile int *)&g_team.fail)) s.ierpj = 1;
+#ifndef RG_LU_TICKS
+#define RG_LU_TICKS 1
+#endif
+    if (!dev_lu(N, c.Pv, c.Lv, c.Uv, c.Dinv, c.wx, c.y, c.lane, RG_LU_TICKS ? part : nullptr, c.wx + ((c.n + 1) & ~1), 0, c.nteam, (volatile int *)&g_team.fail)) s.ierpj = 1;
     cyc_add(CYC_LU, dev_clock() - t0);
     for (int k = 0; k < 4; ++k) cyc_add(CYC_LU_PART + k, part[k]);
   }
