@@ -16,7 +16,7 @@ module racgpu
             racgpu_species_index, racgpu_load_initial_abundances, racgpu_params_default, racgpu_n_record, &
             racgpu_set_tolerances, racgpu_init_abundances, racgpu_set_device, racgpu_device_count, &
             racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_rectify_abundances, &
-            racgpu_set_cost_hints, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
+            racgpu_set_cost_hints, racgpu_set_team_threshold, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
   public :: racgpu_error_string, chemsol_to_c, c_string
 
   integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 20, RACGPU_NOUT = 3, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
@@ -191,6 +191,14 @@ module racgpu
       type(c_ptr), value :: h
       real(c_double), dimension(*), intent(in) :: cost
       integer(c_int64_t), value :: ncell
+      integer(c_int) :: rc
+    end function
+    ! cells expected to cost more than frac x (sum of the hints / wave slots) get a team of four waves (default 0.5; <= 0 never;
+    ! < 0 also switches off the hand-over of the last running cells to teams at the end of a pass); results do not depend on it
+    function racgpu_set_team_threshold(h, frac) bind(c, name='racgpu_set_team_threshold') result(rc)
+      import :: c_ptr, c_double, c_int
+      type(c_ptr), value :: h
+      real(c_double), value :: frac
       integer(c_int) :: rc
     end function
     function racgpu_last_kernel_ms(h) bind(c, name='racgpu_last_kernel_ms') result(ms)

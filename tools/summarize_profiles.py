@@ -85,7 +85,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 fetch_factor = cal["known_bytes"]["k_calib_read_stream_bytes"] / cal["FETCH_SIZE"]["k_calib_read_stream"]["counter_bytes"]
 write_factor = cal["known_bytes"]["k_calib_write_bytes"] / cal["WRITE_SIZE"]["k_calib_write"]["counter_bytes"]
 reread_factor = cal["known_bytes"]["k_calib_read_reread_bytes"] / cal["FETCH_SIZE"]["k_calib_read_reread"]["counter_bytes"]
-ks = allc.get("k_solve", {})
+ks = {}  # the pass's solver kernels together: k_solve, then k_solve_team_resume (k_solve_team alongside when cost hints are in place)
+for k, a in allc.items():
+    if k.startswith("k_solve"):
+        for c, v in a.items():
+            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                ks[c] = ks.get(c, 0.0) + v
 bench = json.load(open(os.path.join(src, "bench_pmc_FETCH_SIZE.json")))
 steps = bench["cell_steps_per_pass_rank0"]
 hbm = ks.get("FETCH_SIZE", 0.0) * 1024 * fetch_factor + ks.get("WRITE_SIZE", 0.0) * 1024 * write_factor
