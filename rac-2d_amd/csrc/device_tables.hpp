@@ -27,6 +27,10 @@ struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, j, pad[6]; 
 // depths and group sizes below: measured on the configs[2] scan, round 2 (profiles/r2_tuning.txt)
 constexpr int kJacUnroll = RG_JAC_UNROLL; // rows of the Jacobian term stream per unrolled step (the stream is padded to a multiple)
 constexpr int kSweepDepth = RG_SWEEP_DEPTH; // chunks of a triangular-solve stream in flight; the schedules are padded to a multiple
+#ifndef RG_TEAM
+#define RG_TEAM 4
+#endif
+constexpr int kTeam = RG_TEAM; // waves of a team (k_solve_team: the cells that would otherwise set the length of a pass)
 constexpr int kLuDepth = RG_LU_DEPTH; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
 
 struct DevNet {
@@ -52,7 +56,7 @@ struct DevNet {
   const uint64_t *jac_stream, *jac_slot;
   const uint32_t *jac_rowflag;
   int jac_rows;
-  int jac_seg_row[5], jac_seg_pass[5]; // the stream in four segments of whole passes (first row / first pass; [4] = the end): k_solve_team
+  int jac_seg_row[kTeam + 1], jac_seg_pass[kTeam + 1]; // the stream in kTeam segments of whole passes (first row / first pass; the last = the end): k_solve_team
   // ---- sparse LU of the permuted species block ----
   const uint16_t *perm;      // perm[new] = old
   const uint16_t *Lrow, *Urow, *Prow; // storage layout: see network.hpp, struct Symbolic
@@ -71,6 +75,10 @@ struct DevNet {
   const unsigned long long *Udesc;
   const LuCol *lucol;        // [nwork+2] the LU's work list (engine.hip, upload): columns with pivots, then the trailing block
   int nwork_sparse, nwork;   // work items with j < ns / in all
+  // k_solve_team: the work items with j < ns again, one list per wave of a team, ordered by dependency level (engine.hip, upload)
+  const LuCol *lucol_team;   // wave w's list starts at team_base[w]
+  const int *team_lev_ptr;   // [kTeam][team_nlev + 1]: where each level starts in the wave's list
+  int team_base[kTeam], team_nlev;
   const unsigned long long *leaf_diag, *leaf_ent; // pivot-free columns, factored elementwise beforehand
   int nleaf, nleaf_ent;
   int nchunkL, nchunkU;

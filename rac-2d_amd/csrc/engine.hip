@@ -267,7 +267,6 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
   solve_body<1, false>(*Np, *Pp, W, A, lds);
 }
 
-constexpr int kTeam = 4;
 __global__ __launch_bounds__(64 * kTeam) void k_solve_team(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
   extern __shared__ double lds[];
   solve_body<kTeam, false>(*Np, *Pp, W, A, lds);
@@ -616,6 +615,45 @@ void racgpu_network::upload() {
       dn.nleaf = (int)leaf_diag.size(); dn.nleaf_ent = (int)leaf_ent.size();
       leaf_diag.resize(leaf_diag.size() + 64, 0ull); leaf_ent.resize(leaf_ent.size() + 64, 0ull);
       dn.leaf_diag = up(leaf_diag); dn.leaf_ent = up(leaf_ent);
+      // k_solve_team: the columns k < ns that have pivots, level by level (a column's level = 1 + the highest level among its
+      // pivots; columns of one level do not feed each other), the columns of a level dealt to the kTeam waves by weight
+      // (pivots + a constant per column, heaviest first to the least loaded wave).  One list per wave, two spare items each.
+      {
+        std::vector<int> lev(nS, 0);
+        int nlev = 0;
+        for (int t = 0; t < nwork_sparse; ++t) {
+          const int j = lc[t].j;
+          int l = 0;
+          for (int q = S.Ucolptr[j]; q < S.Ucolend[j]; ++q) l = std::max(l, lev[S.Urow[q]]);
+          lev[j] = l + 1; nlev = std::max(nlev, l + 1);
+        }
+        std::vector<std::vector<std::vector<int>>> deal(kTeam, std::vector<std::vector<int>>(nlev)); // [wave][level-1] -> work items
+        for (int l = 1; l <= nlev; ++l) {
+          std::vector<int> items;
+          for (int t = 0; t < nwork_sparse; ++t) if (lev[lc[t].j] == l) items.push_back(t);
+          std::stable_sort(items.begin(), items.end(), [&](int a, int b) { return lc[a].d1 - lc[a].d0 > lc[b].d1 - lc[b].d0; });
+          long load[kTeam] = {0};
+          for (int t : items) {
+            const int w = (int)(std::min_element(load, load + kTeam) - load);
+            deal[w][l - 1].push_back(t); load[w] += (lc[t].d1 - lc[t].d0) + 4;
+          }
+        }
+        std::vector<LuCol> tl;
+        std::vector<int> lp; // [kTeam][nlev + 1], positions relative to the wave's own list
+        for (int w = 0; w < kTeam; ++w) {
+          dn.team_base[w] = (int)tl.size();
+          int pos = 0;
+          for (int l = 0; l < nlev; ++l) {
+            lp.push_back(pos);
+            std::sort(deal[w][l].begin(), deal[w][l].end());
+            for (int t : deal[w][l]) { tl.push_back(lc[t]); ++pos; }
+          }
+          lp.push_back(pos);
+          tl.push_back(tl.empty() ? LuCol{} : tl.back()); tl.push_back(tl.back());
+        }
+        dn.team_nlev = nlev;
+        dn.lucol_team = up(tl); dn.team_lev_ptr = up(lp);
+      }
       lc.push_back(lc.empty() ? LuCol{} : lc.back()); lc.push_back(lc.back()); // the column prefetch reads two ahead
       dn.lucol = up(lc);
     }

@@ -398,13 +398,14 @@ RG_DEV void lds_sync() {
 #define RG_CLAMP_LOADS 1
 #endif
 //
-// Team mode (nteam > 1 waves of one workgroup on one cell, k_solve_team): wave 0 factors the columns k < ns as above while the
-// others wait; the trailing columns then go round by round, nteam groups of G columns per round, one group per wave.  What a
+// Team mode (nteam > 1 waves of one workgroup on one cell, k_solve_team): the columns k < ns go dependency level by level, the
+// columns of a level dealt to the waves; the trailing columns then go round by round, nteam groups of G columns per round, one
+// group per wave.  What a
 // group needs from the columns k < ns and from the groups of earlier rounds (its LDS pivots and the dense pivots below the
 // round's first column) is independent of the round's other groups and runs in parallel, each wave on a work column of its own;
 // the rest of the round (the dense pivots that belong to the round's earlier groups, the group among itself, the stores) is
 // taken in turns between barriers.  Every column sees its pivots in the same order as with one wave: the factors are the same
-// to the last bit.  Every wave of the team executes the same number of barriers: 1 + (nteam + 1) * rounds.
+// to the last bit.  Every wave of the team executes the same number of barriers: 2 + levels + (nteam + 1) * rounds.
 RG_DEV void team_barrier() { __syncthreads(); }
 
 RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__restrict__ Lv, double *__restrict__ Uv,
@@ -421,7 +422,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   const rsrc_t bLrow = mkbuf(N.Lrow), bUrow = mkbuf(N.Urow), bProw = mkbuf(N.Prow), bUdesc = mkbuf(N.Udesc), bP = mkbuf(Pv), bL = mkbuf(Lv),
                bU = mkbuf(Uv);
   const int l2 = lane * 2, l8 = lane * 8; // lane part of every byte offset (u16 and 8-byte arrays)
-  const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column
+  const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column (team mode: first the wave's own list)
   auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; r.j = c[9]; return r; };
   for (int i = lane; i < n; i += 64) w[i] = 0.0; // the work column is kept all-zero between columns
   lds_sync();
@@ -547,10 +548,10 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     return t.d;
   };
 
-  // ---- pivot-free columns, all at once: D^-1 = 1/P(j,j), L(:,j) = P(rows > j, j) * D^-1 --------------------------------
-  if (wv == 0) {
+  // ---- pivot-free columns, all at once: D^-1 = 1/P(j,j), L(:,j) = P(rows > j, j) * D^-1 (a team shares the blocks out) ----
+  {
     const rsrc_t bLd = mkbuf(N.leaf_diag), bLe = mkbuf(N.leaf_ent);
-    for (int q0 = 0; q0 < N.nleaf; q0 += 64) {
+    for (int q0 = 64 * wv; q0 < N.nleaf; q0 += 64 * nteam) {
       const unsigned long long e = bload_u64(bLd, l8, q0 * 8);
       if (q0 + lane < N.nleaf) {
         const int jj = (int)(e >> 32);
@@ -561,7 +562,8 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
       }
     }
     lds_sync();
-    for (int q0 = 0; q0 < N.nleaf_ent; q0 += 64) {
+    if (nteam > 1) team_barrier(); // every wave's D^-1 of these columns is in the shared LDS copy
+    for (int q0 = 64 * wv; q0 < N.nleaf_ent; q0 += 64 * nteam) {
       const unsigned long long e = bload_u64(bLe, l8, q0 * 8);
       if (q0 + lane < N.nleaf_ent)
         sstore_f64(bL, (int)((e >> 20) & 0xfffff) * 8, 0, pload_f64(bP, (int)(e & 0xfffff) * 8, 0) * dl[(int)(e >> 40)]);
@@ -570,9 +572,21 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     RG_TICK(c_fin)
   }
 
-  if (wv == 0)
+  if (nteam == 1) {
     for (int c = 0; c < N.nwork_sparse; ++c) { rect_phase(c, w); RG_TICK(c_dense) finish(cur.j, w); }
-  if (nteam > 1) team_barrier(); // the columns k < ns and their D^-1 are in place for the whole team
+  } else {
+    // the columns k < ns that have pivots, dependency level by level: the columns of a level do not feed each other and are dealt
+    // to the waves (device_tables.hpp, lucol_team); a barrier per level
+    team_barrier(); // the pivot-free columns are complete
+    const RG_GLOBAL int *lp = gptr(N.team_lev_ptr) + wv * (N.team_nlev + 1);
+    cols = gptr(reinterpret_cast<const int *>(N.lucol_team)) + 16 * N.team_base[wv];
+    prime(0);
+    for (int l = 0; l < N.team_nlev; ++l) {
+      for (int c = lp[l]; c < lp[l + 1]; ++c) { rect_phase(c, w); RG_TICK(c_dense) finish(cur.j, w); }
+      team_barrier(); // this level's columns and their D^-1 are in place for the whole team
+    }
+    cols = gptr(reinterpret_cast<const int *>(N.lucol));
+  }
 
   // ---- dense trailing block, G columns at a time (G = 12: every L column of the block is read n/12 times, not n times) ----
   // After a column's LDS pivots (k < ns) its entries in rows < ns are final and go straight to U; its tail rows
@@ -623,7 +637,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     const bool active = g0 + wv < ngroups;
     const int ng = active ? min(G, n - j) : 0;
     double wA[G], wB[G];
-    if (nteam > 1 && !(wv == 0 && g0 == 0)) { if (active) prime(N.nwork_sparse + (j - ns)); }
+    if (nteam > 1) { if (active) prime(N.nwork_sparse + (j - ns)); }
 #pragma unroll
     for (int c = 0; c < G; ++c) {
       wA[c] = 0.0; wB[c] = 0.0;
