@@ -15,7 +15,8 @@ def run(cells, tag):
     print("%-34s %.2f s  kernel %.0f ms  team cells %d  total steps %d" % (tag, t1 - t0, net.last_kernel_ms(), net.last_team_cells(), out["stats"][:, 0].sum()))
     return out
 
-SHORT = len(sys.argv) > 1
+SHORT = len(sys.argv) > 1 and sys.argv[1] == 'short'
+HINTED_ONLY = len(sys.argv) > 1 and sys.argv[1] == 'hinted'
 if SHORT:
     idx = [8262, 1054, 9248, 6485]
     cells = allc[idx]
@@ -34,11 +35,13 @@ print("   parked", net.last_parked_cells())
 assert np.array_equal(o1["y"], out["y"]) and np.array_equal(o1["stats"][:, :8], out["stats"][:, :8])
 cost = out["stats"][:, 8].astype(float)
 idx = [int(i) for i in np.argsort(-cost)[:8]]
-for frac in (-1.0, 0.0, 0.5):
+for frac in ((0.5, 0.5) if HINTED_ONLY else (-1.0, 0.0, 0.5)):
     net.set_team_threshold(frac); net.set_cost_hints(cost)
     o2 = run(allc, "full batch, hinted, team frac %g" % frac)
     print("   parked", net.last_parked_cells())
     assert np.array_equal(o2["y"], out["y"]) and np.array_equal(o2["stats"][:, :8], out["stats"][:, :8])
+if HINTED_ONLY:
+    sys.exit(0)
 cells = allc[idx]
 for frac in (0.0, 1e-9):
     net.set_team_threshold(frac); net.set_cost_hints(np.ones(len(idx)))
