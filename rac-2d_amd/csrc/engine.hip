@@ -429,8 +429,10 @@ void racgpu_network::upload() {
     const Kind k = h.kind(r);
     const uint64_t a = k == K_NONE ? 0 : (uint64_t)(x.reac[0] - 1), b = (k == K_TWO) ? (uint64_t)(x.reac[1] - 1) : a;
     w0[r] = (uint64_t)k | ((uint64_t)x.n_reac << 8) | (a << 16) | (b << 32);
+    // unused slots name the spare double of the lane that handles this row (64 of them behind the third LDS vector: index
+    // 2 * nlds + lane seen from ydot, the second vector): the kernel adds to all seven slots without testing
     uint16_t tg[8];
-    for (int s = 0; s < 8; ++s) tg[s] = 0xffff;
+    for (int s = 0; s < 8; ++s) tg[s] = (uint16_t)(2 * ((nS + 1) & ~1) + (r % 64));
     if (k != K_NONE) {
       // slots 0..n_reac-1 are reactants (subtract), then products (add); unused slots stay 0xffff.
       for (int s = 0; s < x.n_reac; ++s) tg[s] = (uint16_t)(x.reac[s] - 1);
@@ -438,6 +440,7 @@ void racgpu_network::upload() {
     }
     w1[r] = (uint64_t)tg[0] | ((uint64_t)tg[1] << 16) | ((uint64_t)tg[2] << 32) | ((uint64_t)tg[3] << 48);
     w2[r] = (uint64_t)tg[4] | ((uint64_t)tg[5] << 16) | ((uint64_t)tg[6] << 32) | ((uint64_t)0xffff << 48);
+    if (2 * ((nS + 1) & ~1) + 63 >= 0xffff) throw std::runtime_error("RHS rows: too many species for 16-bit target slots");
   }
   dn.r_itype = up(itype); dn.r_re0 = up(re0); dn.r_re1 = up(re1); dn.r_nreac = up(nreac); dn.r_fss = up(fss);
   dn.r_flags = up(flags); dn.r_id3 = up(id3);
@@ -448,7 +451,10 @@ void racgpu_network::upload() {
     for (int &v : dl) v -= 1;
     dn.dupli_ptr = up(h.dupli_ptr); dn.dupli_list = up(dl);
   }
-  w0.resize(w0.size() + 448, 0); w1.resize(w1.size() + 448, ~0ull); w2.resize(w2.size() + 448, ~0ull); // padding: the RHS runs to a multiple of 192 rows and prefetches 128 ahead (kind 0, no targets)
+  for (int r = nR; r < nR + 448; ++r) { // padding: the RHS runs to a multiple of 192 rows and prefetches 128 ahead (kind 0: flux = k * y[0], every slot spare)
+    const uint64_t sp = (uint64_t)(2 * ((nS + 1) & ~1) + (r % 64));
+    w0.push_back(0); w1.push_back(sp | (sp << 16) | (sp << 32) | (sp << 48)); w2.push_back(sp | (sp << 16) | (sp << 32) | ((uint64_t)0xffff << 48));
+  }
   dn.rhs_w0 = up(w0); dn.rhs_w1 = up(w1); dn.rhs_w2 = up(w2);
   // Jacobian gather: entries sorted by decreasing term count so that the 64 lanes of a pass do similar work
   {
