@@ -544,17 +544,12 @@ void racgpu_network::upload() {
       for (size_t q = 0; q < S.Psrc.size(); ++q) kr[q] = (uint16_t)h.ref_kref[S.Psrc[q]];
       dn.Pkref = up(kr);
     }
-    const uint32_t spare_row = (uint32_t)((nS + 1) & ~1); // the 64 spare doubles behind the LDS work vector, one per lane
-    if (spare_row + 63 >= 1024) throw std::runtime_error("solve schedule: too many species for 10-bit row indices");
-    auto pack = [spare_row](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, size_t nstream, int &nchunk) {
+    auto pack = [](const std::vector<int> &row, const std::vector<int> &col, const std::vector<int> &lev, size_t nstream, int &nchunk) {
       // the streamed part only (the dense trailing block is solved in registers); the storage is level-aligned, so
-      // every chunk of 64 entries has ONE level; bit 20 of every word of a chunk: the next chunk continues this level.
-      // Null entries (the alignment padding, row == col in the layout) add whatever their value slot holds times x[0] to the
-      // lane's spare double: the sweep has no test for them.
-      auto null_word = [spare_row](size_t e) { return spare_row + (uint32_t)(e % 64); };
+      // every chunk of 64 entries has ONE level; bit 20 of every word of a chunk: the next chunk continues this level
       std::vector<uint32_t> rc(nstream);
-      for (size_t e = 0; e < nstream; ++e) rc[e] = row[e] == col[e] ? null_word(e) : ((uint32_t)row[e] | ((uint32_t)col[e] << 10));
-      while (rc.size() % 64) rc.push_back(null_word(rc.size()));
+      for (size_t e = 0; e < nstream; ++e) rc[e] = (uint32_t)row[e] | ((uint32_t)col[e] << 10);
+      rc.resize((nstream + 63) / 64 * 64, 0u); // row == col == 0: skipped
       size_t nch = rc.size() / 64;
       auto chunk_level = [&](size_t c) { return lev[std::min(c * 64, nstream - 1)]; };
       for (size_t c = 0; c < nch; ++c) {
@@ -563,7 +558,7 @@ void racgpu_network::upload() {
         if (c + 1 < nch && chunk_level(c + 1) == chunk_level(c))
           for (size_t e = c * 64; e < (c + 1) * 64; ++e) rc[e] |= 1u << 20;
       }
-      while (nch % kSweepDepth) { for (int l = 0; l < 64; ++l) rc.push_back(null_word(l)); ++nch; } // null chunks: the sweep is unrolled by its depth
+      while (nch % kSweepDepth) { rc.resize(rc.size() + 64, 0u); ++nch; } // null chunks: the sweep is unrolled by its depth
       nchunk = (int)nch;
       rc.resize(rc.size() + 16 * 64, 0u); // spare chunks: the sweep prefetches unconditionally
       return rc;

@@ -709,7 +709,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 }
 
 // One triangular sweep over the streamed part: entries come in dependency-level order, 64 per chunk, one level per
-// chunk (the storage is level-aligned); every entry does x[row] -= v * x[col] (w must have 64 spare doubles behind it).  Within a level the columns are
+// chunk (the storage is level-aligned); every entry does x[row] -= v * x[col].  Within a level the columns are
 // independent; entries of different columns may hit the same row, hence the LDS atomic (no return: the wave never
 // waits for it).  Schedule words and values are kSweepDepth-1 chunks ahead in registers; the x[col] of the next
 // chunk are read from LDS before this chunk's updates are issued whenever that chunk continues the level, so a
@@ -736,7 +736,7 @@ RG_DEV void dev_tri_sweep(const uint32_t *__restrict__ rc, const double *__restr
       if (!have) { lds_order(); x = w[col]; }
       double xn = 0.0;
       if (cont) xn = w[(wn >> 10) & 1023u];
-      atomicAdd(&w[row], -(v[s] * x)); // (null entries name the lane's spare double behind w)
+      if (row != col) atomicAdd(&w[row], -(v[s] * x));
       have = cont; x = xn;
     }
   }
