@@ -542,6 +542,13 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     RG_TICK(c_fin)
   };
 
+  auto rlane = [&](double v, int src) -> double { // v of lane src
+    union { double d; int i[2]; } s, t;
+    s.d = v;
+    t.i[0] = __builtin_amdgcn_readlane(s.i[0], src);
+    t.i[1] = __builtin_amdgcn_readlane(s.i[1], src);
+    return t.d;
+  };
   auto bcast = [&](double a, double b, int kk) -> double { // value held by the lane that owns tail row ns + kk
     union { double d; int i[2]; } s, t;
     s.d = (kk < 64) ? a : b;
@@ -604,36 +611,47 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 #ifndef RG_DENSE_AHEAD
 #define RG_DENSE_AHEAD 2 // L columns of the block per register set (two sets: one being applied, one in flight)
 #endif
-  static_assert(RG_DENSE_G % (2 * RG_DENSE_AHEAD) == 0, "a group's first column must start a pair of register sets");
-#define RG_DENSE_LOAD(LA, LB, kb_, kend_)                                                                        \
-  _Pragma("unroll") for (int u = 0; u < RG_DENSE_AHEAD; ++u) {                                                                \
+  static_assert(RG_DENSE_G % (2 * RG_DENSE_AHEAD) == 0 && 64 % (2 * RG_DENSE_AHEAD) == 0, "a group's first column and row 64 of the block must start a pair of register sets");
+  // Lane l holds rows ns + l ("A": wA) and ns + 64 + l ("B": wB) of every column of the group.  A pivot among the first 64 rows of
+  // the block (FIRST) takes its multipliers from wA, touches the A rows below it (select on the L values) and all B rows; a later
+  // one takes them from wB and touches B rows only: nothing is loaded or computed for A.  A range of pivots is cut at row 64 of
+  // the block (a multiple of the register sets' stride), so each loop is of one kind.  Lanes whose row lies outside the matrix
+  // carry garbage that is never stored or broadcast.
+#define RG_DENSE_LOAD(LA, LB, kb_, kend_, FIRST)                                                                 \
+  _Pragma("unroll") for (int u = 0; u < RG_DENSE_AHEAD; ++u) {                                                   \
     const int k = min((kb_) + u, max((kend_) - 1, ns)), kk = k - ns;                                              \
     const int cb = ((nzls + kk * (nt - 1) - kk * (kk - 1) / 2) - k - 1) * 8; /* byte offset of L(0, k): L(row, k) sits row*8 further */ \
-    const double va = sload_f64(bL, rA8, cb), vb = sload_f64(bL, rB8, cb); /* unconditional: rows outside the column read neighbouring entries */ \
-    LA[u] = (rowA > k && rowA < n) ? va : 0.0;                                                                    \
-    LB[u] = (rowB > k && rowB < n) ? vb : 0.0;                                                                    \
+    const double vb = sload_f64(bL, rB8, cb); /* unconditional: rows outside the column read neighbouring entries */ \
+    if (FIRST) { const double va = sload_f64(bL, rA8, cb); LA[u] = (lane > kk) ? va : 0.0; LB[u] = vb; }          \
+    else LB[u] = (lane > kk - 64) ? vb : 0.0;                                                                     \
   }
-#define RG_DENSE_APPLY(LA, LB, kb_, kend_)                                                                       \
-  _Pragma("unroll") for (int u = 0; u < RG_DENSE_AHEAD; ++u) {                                                                \
-    const int k = (kb_) + u;                                                                                      \
+#define RG_DENSE_APPLY(LA, LB, kb_, kend_, FIRST)                                                                \
+  _Pragma("unroll") for (int u = 0; u < RG_DENSE_AHEAD; ++u) {                                                   \
+    const int k = (kb_) + u, kk = k - ns;                                                                         \
     if (k < (kend_)) {                                                                                            \
       _Pragma("unroll") for (int c = 0; c < G; ++c) {                                                            \
-        const double t = bcast(wA[c], wB[c], k - ns);                                                             \
-        wA[c] -= LA[u] * t; wB[c] -= LB[u] * t;                                                                   \
+        if (FIRST) { const double t = rlane(wA[c], kk); wA[c] -= LA[u] * t; wB[c] -= LB[u] * t; }                 \
+        else wB[c] -= LB[u] * rlane(wB[c], kk - 64);                                                              \
       }                                                                                                           \
+    }                                                                                                             \
+  }
+#define RG_DENSE_RANGE1(kbeg_, kend_, FIRST)                                                                     \
+  if ((kend_) > (kbeg_)) {                                                                                        \
+    double la0[RG_DENSE_AHEAD], lb0[RG_DENSE_AHEAD], la1[RG_DENSE_AHEAD], lb1[RG_DENSE_AHEAD];                    \
+    RG_DENSE_LOAD(la0, lb0, (kbeg_), (kend_), FIRST)                                                              \
+    for (int kb = (kbeg_); kb < (kend_); kb += 2 * RG_DENSE_AHEAD) {                                              \
+      RG_DENSE_LOAD(la1, lb1, kb + RG_DENSE_AHEAD, (kend_), FIRST)                                                \
+      RG_DENSE_APPLY(la0, lb0, kb, (kend_), FIRST)                                                                \
+      RG_DENSE_LOAD(la0, lb0, kb + 2 * RG_DENSE_AHEAD, (kend_), FIRST)                                            \
+      RG_DENSE_APPLY(la1, lb1, kb + RG_DENSE_AHEAD, (kend_), FIRST)                                               \
     }                                                                                                             \
   }
   // pivots kbeg <= k < kend of the block on the group's columns (kbeg - ns is a multiple of G, hence of 2 * RG_DENSE_AHEAD)
 #define RG_DENSE_RANGE(kbeg_, kend_)                                                                             \
-  if ((kend_) > (kbeg_)) {                                                                                        \
-    double la0[RG_DENSE_AHEAD], lb0[RG_DENSE_AHEAD], la1[RG_DENSE_AHEAD], lb1[RG_DENSE_AHEAD];                                                                        \
-    RG_DENSE_LOAD(la0, lb0, (kbeg_), (kend_))                                                                     \
-    for (int kb = (kbeg_); kb < (kend_); kb += 2 * RG_DENSE_AHEAD) {                                                               \
-      RG_DENSE_LOAD(la1, lb1, kb + RG_DENSE_AHEAD, (kend_))                                                                    \
-      RG_DENSE_APPLY(la0, lb0, kb, (kend_))                                                                       \
-      RG_DENSE_LOAD(la0, lb0, kb + 2 * RG_DENSE_AHEAD, (kend_))                                                                    \
-      RG_DENSE_APPLY(la1, lb1, kb + RG_DENSE_AHEAD, (kend_))                                                                   \
-    }                                                                                                             \
+  {                                                                                                               \
+    const int kcut_ = ns + 64;                                                                                    \
+    RG_DENSE_RANGE1((kbeg_), min((kend_), kcut_), true)                                                           \
+    RG_DENSE_RANGE1(max((kbeg_), kcut_), (kend_), false)                                                          \
   }
   for (int g0 = 0; g0 < ngroups; g0 += nteam) { // one round: groups g0 .. g0 + nteam - 1, this wave's is g0 + wv
     const int j = ns + G * (g0 + wv), jround = ns + G * g0; // first column of the group / of the round
@@ -700,6 +718,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     }
   }
 #undef RG_DENSE_RANGE
+#undef RG_DENSE_RANGE1
 #undef RG_DENSE_LOAD
 #undef RG_DENSE_APPLY
   if (nteam > 1) ok = *tfail == 0;
