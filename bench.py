@@ -356,7 +356,7 @@ def main():
                        "parallelism": "cells sharded over %d GPU(s) (%s), one RCCL all-gather of abundances + t_final + quality + counters at output" % (world, args.scaling),
                        "local_iterations": args.nlocal_iter,
                        # cells the last pass gave to four-wave teams: from the start (cost hints; racgpu_set_team_threshold) / between
-                       # two integrator steps once the queue was empty and at most one wave per CU was left
+                       # two integrator steps once the queue was empty and at most two waves per CU were left
                        "cells_in_teams": {"from_start": teams[0], "handed_over": teams[1]},
                        "scheduling": ("costliest-first from the previous pass's per-cell cycle counts (racgpu_set_cost_hints)" if hinted
                                       else "queue order (no previous pass to take cost hints from)"),

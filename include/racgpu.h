@@ -205,7 +205,7 @@ int racgpu_set_cost_hints(racgpu_network *, const double *cost, int64_t ncell);
 /* With cost hints in place, a cell whose expected cost exceeds frac x (sum of the costs / wave slots of the GPU) -- a cell that
  * would take that share of the pass's ideal length all by itself -- is solved by a team of four waves (at most one team per CU),
  * started ahead of the rest.  Same arithmetic in the same order: results do not depend on it.  Default 0.5; frac <= 0: never.
- * Independently of hints, the cells still being integrated when the queue is empty and at most one wave per CU is left are handed
+ * Independently of hints, the cells still being integrated when the queue is empty and at most two waves per CU are left are handed
  * over to teams between two output times (frac < 0 switches that off as well). */
 int racgpu_set_team_threshold(racgpu_network *, double frac);
 /* cells the last solve pass gave to teams */

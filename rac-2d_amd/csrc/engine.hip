@@ -1131,9 +1131,11 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
     A.cell_out = B.cell_out ? B.cell_out + (size_t)c0 * RACGPU_NOUT : nullptr;
     A.order = hinted ? h->order_dev + c0 : nullptr;
     A.slot0 = 0;
-    // Cells still being integrated once the queue is empty and at most one wave per CU is left are parked between two output
-    // times and taken up by teams (k_solve_team_resume): the end of a pass is a handful of cells on an otherwise idle chip.
-    const int park_max = h->park_enabled ? h->cu_count : 0;
+    // Cells still being integrated once the queue is empty and at most two waves per CU are left are parked between two integrator
+    // steps and taken up by teams (k_solve_team_resume): the end of a pass is a handful of cells on an otherwise idle chip.
+    int park_per_cu = 2; // (1 / 2 / 3 per CU: 7742 / 7661 / 7659 ms on the configs[2] scan, 11.93 / 11.86 / 11.87 s on configs[1] without hints)
+    if (const char *e = std::getenv("RACGPU_PARK_PER_CU")) park_per_cu = std::max(1, std::atoi(e)); // developer aid
+    const int park_max = h->park_enabled ? h->cu_count * park_per_cu : 0;
     A.park_max = park_max; A.park_list = h->ws.counter + 16; A.park_count = h->ws.counter + 4;
     // Cells that would take more than team_frac of the pass's ideal length on their own (sum of costs / wave slots) go to
     // k_solve_team, four waves each, on a second stream and ahead of the bulk kernel; they are the head of the sorted order.

@@ -17,6 +17,7 @@ def run(cells, tag):
 
 SHORT = len(sys.argv) > 1 and sys.argv[1] == 'short'
 HINTED_ONLY = len(sys.argv) > 1 and sys.argv[1] == 'hinted'
+UNHINTED_ONLY = len(sys.argv) > 1 and sys.argv[1] == 'unhinted'
 if SHORT:
     idx = [8262, 1054, 9248, 6485]
     cells = allc[idx]
@@ -26,6 +27,11 @@ if SHORT:
         st = o3["stats"]
         for k, i in enumerate(idx):
             print("cell %5d: cyc=%.2fe9 | per LU %.2fM (scatter %.2f rect %.2f dense %.2f fin %.2f)" % (i, st[k, 8] / 1e9, st[k, 11] / st[k, 3] / 1e6, st[k, 13] / st[k, 3] / 1e6, st[k, 14] / st[k, 3] / 1e6, st[k, 15] / st[k, 3] / 1e6, (st[k, 11] - st[k, 13] - st[k, 14] - st[k, 15]) / st[k, 3] / 1e6))
+    sys.exit(0)
+if UNHINTED_ONLY:
+    net.set_team_threshold(0.5)
+    for rep in range(2):
+        o1 = run(allc, "full batch, queue order, hand-over"); print("   parked", net.last_parked_cells())
     sys.exit(0)
 net.set_team_threshold(-1.0)
 out = run(allc, "full batch, queue order, no teams")
