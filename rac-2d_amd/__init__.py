@@ -17,6 +17,7 @@ import numpy as np
 
 from . import cells  # noqa: F401  (synthetic cell records)
 from . import analysis  # noqa: F401  (rate dump, contributions, elemental reservoirs)
+from . import sweep  # noqa: F401  (sharding over ranks, layer-by-layer sweeps)
 from .cells import NPAR
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -165,3 +165,67 @@ def andrews_grid(ncol=200, nz=100, rmin=0.1, rmax=200.0, zr_max=0.6, star_mass_m
     if return_geometry:
         return cells, np.ascontiguousarray(R.reshape(-1)), np.ascontiguousarray(Z.reshape(-1))
     return cells
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Self-shielding factors of a cell from the column densities above it: the part of the caller's update_params_above_alt
+# (reference src/disk.f90:1823-1883) that only needs numbers, for sweeps that refresh the records of a layer from the layers
+# solved before it (sweep.solve_by_layers).  The column densities themselves come from the caller's grid (the reference traces
+# rays through its quadtree, calc_Ncol_from_cell_to_point: out of scope); column_density_above does the vertical sum of a
+# regular column grid.
+# ---------------------------------------------------------------------------------------------------------
+LYA_CROSS_H2O = 1.2e-17   # const_LyAlpha_cross_H2O, reference src/sub_global_variables.f90:82
+LYA_CROSS_OH = 1.8e-18    # const_LyAlpha_cross_OH, :83
+
+
+def h2_self_shielding(N_H2, dv_turb):
+    """min(1, Draine & Bertoldi 1996 eq. 37): get_H2_self_shielding, reference src/disk.f90:1887-1897, as update_params_above_alt
+    caps it (:1840-1843).  N_H2 [cm^-2], dv_turb [cm/s].  The second coefficient is a single-precision literal in the
+    reference (0.035 without D0)."""
+    x = np.asarray(N_H2, dtype=np.float64) / 5e14
+    b5 = np.asarray(dv_turb, dtype=np.float64) / 1e5
+    tmp = np.sqrt(1.0 + x)
+    f = 0.965 / (1.0 + x / b5) ** 2 + np.float64(np.float32(0.035)) / tmp * np.exp(-8.5e-4 * tmp)
+    return np.minimum(1.0, f)
+
+
+def lya_self_shielding(N_col, cross_section):
+    """min(1, exp(-N sigma)): the H2O and OH factors of update_params_above_alt (reference src/disk.f90:1847-1859) with
+    LYA_CROSS_H2O / LYA_CROSS_OH."""
+    return np.minimum(1.0, np.exp(-(np.asarray(N_col, dtype=np.float64) * cross_section)))
+
+
+def co_shielding(table, N_H2, N_12CO):
+    """12CO shielding by H2 and by itself from a caller-supplied table, with the algorithm of get_12CO_shielding (reference
+    src/load_Visser_CO_selfshielding.f90:271-309): log10 of the column densities (floored at 1 cm^-2), the enclosing table
+    cell (the last one beyond the table, the first one below it), four-point linear interpolation of ln f
+    (calc_four_point_linear_interpol, src/sub_trivials.f90:803-821), clamped to [0, 1] as update_params_above_alt does.
+    table = (logN_H2 [nrow], logN_12CO [ncol], f [ncol, nrow]), both axes ascending.  The reference's own table (Visser et
+    al. 2009) is compiled into it; here it is the caller's data."""
+    lh, lc, f = (np.asarray(a, dtype=np.float64) for a in table)
+    x = np.log10(np.maximum(np.asarray(N_12CO, dtype=np.float64), 1.0))
+    y = np.log10(np.maximum(np.asarray(N_H2, dtype=np.float64), 1.0))
+    i1 = np.clip(np.searchsorted(lh, y, side="left") - 1, 0, lh.size - 2)
+    j1 = np.clip(np.searchsorted(lc, x, side="left") - 1, 0, lc.size - 2)
+    x1, x2, y1, y2 = lc[j1], lc[j1 + 1], lh[i1], lh[i1 + 1]
+    z11, z12, z21, z22 = np.log(f[j1, i1]), np.log(f[j1, i1 + 1]), np.log(f[j1 + 1, i1]), np.log(f[j1 + 1, i1 + 1])
+    k1 = (z12 - z11) / (y2 - y1)
+    k2 = (z22 - z21) / (y2 - y1)
+    v = ((k2 - k1) / (x2 - x1) * (x - x1) + k1) * (y - y1) + (z21 - z11) / (x2 - x1) * (x - x1) + z11
+    return np.minimum(1.0, np.maximum(0.0, np.exp(v)))
+
+
+def column_density_above(n_species, dz, column, layer):
+    """Column density [cm^-2] from the TOP of every cell of a regular column grid to the surface: the sum of n dz over the cells
+    of the same column in the layers above it (layer 0 = the top; the cell itself is not counted, as with the reference's
+    fromCellCenter = .false., src/disk.f90:2532-2537).  n_species [ncell] = n_gas * abundance."""
+    n_species = np.asarray(n_species, dtype=np.float64)
+    out = np.zeros_like(n_species)
+    order = np.lexsort((np.asarray(layer), np.asarray(column)))
+    col_sorted = np.asarray(column)[order]
+    contrib = (n_species * np.asarray(dz, dtype=np.float64))[order]
+    csum = np.cumsum(contrib) - contrib  # exclusive
+    first = np.r_[True, col_sorted[1:] != col_sorted[:-1]]
+    base = np.maximum.accumulate(np.where(first, np.arange(order.size), 0))
+    out[order] = csum - csum[base]
+    return out

@@ -66,3 +66,39 @@ def solve_sharded(solve_local, cells, y, dist=None, device=None, cost=None):
         full[order[a:b]] = out[r, :b - a]
     return dict(y=np.ascontiguousarray(full[:, :nS]), t_final=full[:, nS].copy(), quality=full[:, nS + 1].astype(np.int32),
                 stats=np.rint(full[:, nS + 2:]).astype(np.int64))
+
+
+def solve_by_layers(solve, cells, y, layer, update=None):
+    """The caller's sweep in dependency order: the reference solves a cell only after the cells above it, because the
+    self-shielding factors in its record are integrals over what those cells ended with (update_params_above_alt, reference
+    src/disk.f90:1823-1883; the list of cells that may be solved next is kept by update_calculating_cells, :1937).  Here every
+    LAYER is one batch: layer 0 (the surface) first, then for each further layer ``update(k, idx, cells, y_done, done)`` may
+    rewrite the records ``cells[idx]`` of that layer from the end states ``y_done`` of all cells solved so far (``done``: their
+    indices) before the layer is solved as one batch.  Layers of a few hundred cells do not fill the GPU with one wave per
+    cell; the engine hands them to four-wave teams by itself.
+
+    solve(cells_block, y_block) -> dict(y, t_final, quality, stats) (e.g. a closure over Network.evol_solve_batch);
+    cells [ncell, NPAR] (modified in place by ``update``), y [ncell, nS] start abundances, layer [ncell] ints.
+    Returns dict(y, t_final, quality, stats) in the caller's cell order."""
+    cells = np.asarray(cells)
+    y_out = np.array(y, dtype=np.float64, copy=True)
+    layer = np.asarray(layer)
+    ncell = cells.shape[0]
+    t_final = np.zeros(ncell)
+    quality = np.zeros(ncell, np.int32)
+    stats = None
+    done = np.zeros(0, dtype=np.int64)
+    for k in np.unique(layer):
+        idx = np.nonzero(layer == k)[0]
+        if update is not None and done.size:
+            update(int(k), idx, cells, y_out, done)
+        res = solve(np.ascontiguousarray(cells[idx]), np.ascontiguousarray(y_out[idx]))
+        y_out[idx] = res["y"]
+        t_final[idx] = res["t_final"]
+        quality[idx] = res["quality"]
+        st = np.asarray(res["stats"], np.int64).reshape(idx.size, -1)
+        if stats is None:
+            stats = np.zeros((ncell, st.shape[1]), np.int64)
+        stats[idx] = st
+        done = np.concatenate([done, idx])
+    return dict(y=y_out, t_final=t_final, quality=quality, stats=stats if stats is not None else np.zeros((0, 0), np.int64))

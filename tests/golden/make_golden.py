@@ -222,8 +222,32 @@ def main_policy():
         print(k, "\n", out[k])
 
 
+def main_shielding():
+    """tests/golden/shielding.npz: the reference's self-shielding functions (oracle/_ref/ref_shielding) at seeded points.
+    H2: 256 points.  CO: the function sampled on a coarse node grid of OURS (the table the product helper is then given) and at
+    256 points in between (what bilinear interpolation of ln f on that coarser grid must reproduce to a few per cent)."""
+    rng = np.random.default_rng(20240607)
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_shielding")
+    def call(kind, a, b):
+        inp = "".join("%s %.17e %.17e\n" % (kind, x, y) for x, y in zip(a, b))
+        out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.split()
+        return np.array([float(v) for v in out])
+    nh2 = 10.0 ** rng.uniform(8.0, 24.0, 256); dv = 10.0 ** rng.uniform(4.3, 5.7, 256)
+    f_h2 = call("H2", nh2, dv)
+    lh = np.r_[0.0, np.arange(15.0, 23.01, 0.5)]; lc = np.r_[0.0, np.arange(10.0, 19.01, 0.5)]
+    gh, gc = np.meshgrid(lh, lc)  # [ncol, nrow]
+    f_nodes = call("CO", 10.0 ** gh.ravel(), 10.0 ** gc.ravel()).reshape(gh.shape)
+    ph = 10.0 ** rng.uniform(14.0, 23.5, 256); pc = 10.0 ** rng.uniform(9.0, 19.5, 256)
+    f_pts = call("CO", ph, pc)
+    np.savez_compressed(os.path.join(HERE, "shielding.npz"), h2_N=nh2, h2_dv=dv, h2_f=f_h2, co_logN_H2=lh, co_logN_12CO=lc,
+                        co_f_nodes=f_nodes, co_N_H2=ph, co_N_12CO=pc, co_f=f_pts)
+    print("wrote shielding.npz")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "policy":
+    if len(sys.argv) > 1 and sys.argv[1] == "shielding":
+        main_shielding()
+    elif len(sys.argv) > 1 and sys.argv[1] == "policy":
         main_policy()
     else:
         main()

@@ -1,0 +1,136 @@
+"""The caller's sweep in dependency order (reference update_params_above_alt + update_calculating_cells, src/disk.f90:1823-1883,
+1937): self-shielding helpers against the reference's own functions (tests/golden/shielding.npz, made by
+tests/golden/make_golden.py shielding from oracle/_ref/ref_shielding), and the layer-by-layer sweep of rac-2d_amd/sweep.py.
+
+CO: the reference's table (Visser et al. 2009) is compiled into it and not shipped here; the fixture holds the reference function
+sampled on a coarser node grid of ours.  co_shielding is therefore pinned AT those nodes (where any table gives the table) and
+to a few per cent in between (bilinear interpolation of ln f on a grid 2.5 times coarser than the reference's): parity of the
+interpolation between the reference's own nodes is unpinned."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+R = importlib.import_module("rac-2d_amd")
+G = np.load(os.path.join(ROOT, "tests", "golden", "shielding.npz"))
+
+
+def test_h2_self_shielding_is_the_references():
+    f = R.cells.h2_self_shielding(G["h2_N"], G["h2_dv"])
+    want = np.minimum(1.0, G["h2_f"])
+    np.testing.assert_allclose(f, want, rtol=4e-15, atol=0)  # pow/exp/sqrt of two libms
+
+
+def test_lya_factors():
+    N = np.array([0.0, 1e15, 1e17, 1e19])
+    np.testing.assert_array_equal(R.cells.lya_self_shielding(N, R.cells.LYA_CROSS_H2O), np.minimum(1.0, np.exp(-(N * 1.2e-17))))
+    np.testing.assert_array_equal(R.cells.lya_self_shielding(N, R.cells.LYA_CROSS_OH), np.minimum(1.0, np.exp(-(N * 1.8e-18))))
+
+
+def test_co_shielding_on_a_table_sampled_from_the_reference():
+    table = (G["co_logN_H2"], G["co_logN_12CO"], G["co_f_nodes"])
+    gh, gc = np.meshgrid(10.0 ** G["co_logN_H2"], 10.0 ** G["co_logN_12CO"])
+    at_nodes = R.cells.co_shielding(table, gh.ravel(), gc.ravel()).reshape(gh.shape)
+    np.testing.assert_allclose(at_nodes, np.clip(G["co_f_nodes"], 0.0, 1.0), rtol=2e-13)
+    between = R.cells.co_shielding(table, G["co_N_H2"], G["co_N_12CO"])
+    want = np.clip(G["co_f"], 0.0, 1.0)
+    err = np.abs(between / want - 1.0)  # steepest where f < 1e-4 (N_H2 > 1e22): a factor of two there on this coarse grid
+    assert np.median(err) < 0.02 and np.quantile(err, 0.9) < 0.15 and np.max(np.abs(np.log10(between / want))) < 0.5
+    # beyond the table: the last cell is extrapolated, below it the first one (reference :278-301)
+    assert R.cells.co_shielding(table, 1e30, 1e25) <= R.cells.co_shielding(table, 1e23, 1e19)
+    assert R.cells.co_shielding(table, 1.0, 1.0) == pytest.approx(min(1.0, G["co_f_nodes"][0, 0]), rel=1e-12)
+
+
+def test_column_density_above_is_an_exclusive_sum_per_column():
+    rng = np.random.default_rng(3)
+    ncol, nlay = 7, 5
+    column = np.repeat(np.arange(ncol), nlay); layer = np.tile(np.arange(nlay), ncol)
+    perm = rng.permutation(ncol * nlay)
+    n = rng.uniform(1.0, 2.0, ncol * nlay); dz = rng.uniform(0.5, 1.5, ncol * nlay)
+    got = R.cells.column_density_above(n[perm], dz[perm], column[perm], layer[perm])
+    want = np.zeros(ncol * nlay)
+    for c in range(ncol):
+        acc = 0.0
+        for l in range(nlay):
+            want[c * nlay + l] = acc
+            acc += n[c * nlay + l] * dz[c * nlay + l]
+    np.testing.assert_allclose(got, want[perm], rtol=1e-13)
+
+
+def test_layers_are_solved_top_down_with_the_update_in_between():
+    """Host logic with a stand-in solver: every layer sees the end states of all layers above it, nothing else."""
+    ncell, nS = 12, 3
+    layer = np.array([2, 0, 1, 0, 2, 1, 3, 3, 0, 1, 2, 3])
+    cells = np.zeros((ncell, R.NPAR)); y = np.arange(ncell * nS, dtype=float).reshape(ncell, nS)
+    calls = []
+
+    def solve(cb, yb):
+        calls.append(cb[:, 0].copy())
+        return dict(y=yb + 100.0 + cb[:, :1], t_final=np.full(len(cb), 7.0), quality=np.zeros(len(cb), np.int32),
+                    stats=np.ones((len(cb), 4), np.int64))
+
+    def update(k, idx, cells_, y_done, done):
+        assert set(layer[done]) == set(range(k)) and not set(idx) & set(done)
+        cells_[idx, 0] = y_done[done].sum()  # something only the finished layers determine
+
+    out = R.sweep.solve_by_layers(solve, cells, y, layer, update)
+    assert len(calls) == 4 and (calls[0] == 0).all()
+    # replay by hand
+    yy = y.copy(); cc = np.zeros((ncell, R.NPAR)); done = np.zeros(0, int)
+    for k in range(4):
+        idx = np.nonzero(layer == k)[0]
+        if done.size:
+            cc[idx, 0] = yy[done].sum()
+        yy[idx] = yy[idx] + 100.0 + cc[idx, :1]
+        done = np.r_[done, idx]
+    np.testing.assert_array_equal(out["y"], yy)
+    assert (out["t_final"] == 7.0).all() and out["stats"].shape == (ncell, 4)
+
+
+@pytest.mark.gpu
+def test_layer_sweep_on_a_small_grid_feeds_shielding_downwards(racgpu):
+    """8 columns x 6 layers of the synthetic grid: a layer-by-layer sweep that recomputes the H2, H2O and OH shielding of a layer
+    from the column densities the layers above ended with gives what solving the layers one by one by hand gives, bit for bit,
+    and differs from the frozen-record (Jacobi) sweep where shielding matters."""
+    net = racgpu.Network(os.path.join(ROOT, "data", "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat"))
+    y0 = net.load_initial_abundances(os.path.join(ROOT, "data", "ini_abund_waterice_loMetal.dat"))
+    grid = racgpu.cells.andrews_grid(ncol=8, nz=6)
+    ncell = grid.shape[0]
+    column = np.repeat(np.arange(8), 6); layer = 5 - np.tile(np.arange(6), 8)  # andrews_grid runs upwards within a column
+    dz = np.full(ncell, 1e13)
+    p = racgpu.default_params(); p.t_max = 1e3
+    grid[:, racgpu.cells.P_TMAX] = 0.0
+    iH2, iH2O, iOH = (net.species_index(nm) - 1 for nm in ("H2", "H2O", "OH"))  # (1-based, as in the reference)
+    assert min(iH2, iH2O, iOH) >= 0
+    C = racgpu.cells
+
+    def update(k, idx, cells_, y_done, done):
+        n = np.zeros(ncell)
+        for sp, slot, f in ((iH2, C.P_FSS_ISM_H2, lambda N: C.h2_self_shielding(N, 1e5)),
+                            (iH2O, C.P_FSS_ISM_H2O, lambda N: C.lya_self_shielding(N, C.LYA_CROSS_H2O)),
+                            (iOH, C.P_FSS_ISM_OH, lambda N: C.lya_self_shielding(N, C.LYA_CROSS_OH))):
+            n[:] = 0.0
+            n[done] = cells_[done, C.P_NGAS] * y_done[done, sp]
+            cells_[idx, slot] = f(C.column_density_above(n, dz, column, layer)[idx])
+
+    solve = lambda cb, yb: net.evol_solve_batch(p, cb, yb)
+    cells_a = grid.copy()
+    out = racgpu.sweep.solve_by_layers(solve, cells_a, net.init_abundances(y0, grid), layer, update)
+    # by hand
+    cells_b = grid.copy(); yb = net.init_abundances(y0, grid); done = np.zeros(0, int)
+    for k in range(6):
+        idx = np.nonzero(layer == k)[0]
+        if done.size:
+            update(k, idx, cells_b, yb, done)
+        r = net.evol_solve_batch(p, np.ascontiguousarray(cells_b[idx]), np.ascontiguousarray(yb[idx]))
+        yb[idx] = r["y"]; done = np.r_[done, idx]
+    np.testing.assert_array_equal(out["y"], yb)
+    np.testing.assert_array_equal(cells_a, cells_b)
+    assert (out["quality"] == 0).all() and (out["t_final"] == 1e3).all()
+    jacobi = net.evol_solve_batch(p, grid, net.init_abundances(y0, grid))
+    top = layer == 0
+    np.testing.assert_array_equal(out["y"][top], jacobi["y"][top])     # the surface layer has nothing above it
+    assert not np.array_equal(out["y"][~top], jacobi["y"][~top])       # below, the records differ
