@@ -201,6 +201,17 @@ int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
  * the previous global iteration of the disk model; waves then take cells in order of decreasing cost, so the few
  * cells that need many times the median work start first instead of last.  Results do not depend on the order.
  * The hint applies while ncell matches; cost == NULL or ncell == 0 clears it. */
+/* The caller's sweep in dependency order, for grids whose cells form columns (reference: a cell is solved once the cells above
+ * it are done, update_calculating_cells src/disk.f90:1937, because update_params_above_alt :1823-1883 puts integrals over their
+ * end states into its record).  Column c holds cells col_cells[col_ptr[c] .. col_ptr[c+1]) from the surface downwards; every
+ * column is solved top down by one team of four waves, columns side by side.  Before a cell is solved, the toISM self-shielding
+ * slots of its record are rewritten from the column densities N = sum n_gas X dz of the cells above it: H2 by
+ * get_H2_self_shielding(N_H2, dv_turb) (:1887-1897), H2O and OH by exp(-N sigma_Lya) (:1847-1859), all capped at 1; the CO slot
+ * and the toStar slots stay as given (they need the reference's tables / ray tracing).  cells is updated in place; everything
+ * else as racgpu_evol_solve_batch with t0 = 0 and the handle's default tolerance policy. */
+int racgpu_column_sweep(racgpu_network *, const racgpu_params *, int64_t ncolumn, const int32_t *col_ptr, const int32_t *col_cells,
+                        int64_t ncell, double *cells, double *y, const double *dz, double dv_turb, double *t_final, int32_t *quality,
+                        int64_t *stats, double *cell_out, int mem);
 int racgpu_set_cost_hints(racgpu_network *, const double *cost, int64_t ncell);
 /* With cost hints in place, a cell whose expected cost exceeds frac x (sum of the costs / wave slots of the GPU) -- a cell that
  * would take that share of the pass's ideal length all by itself -- is solved by a team of four waves (at most one team per CU),

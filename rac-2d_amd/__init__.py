@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "racgpu_species_attrs", "racgpu_species_elements", "racgpu_reaction_rows", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
-    "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_rectify_abundances",
+    "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_column_sweep", "racgpu_rectify_abundances",
     "racgpu_set_cost_hints", "racgpu_set_team_threshold", "racgpu_last_team_cells", "racgpu_last_parked_cells", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
 ]
 
@@ -113,6 +113,8 @@ def lib():
     L.racgpu_set_cost_hints.argtypes = [vp, dp, C.c_int64]
     L.racgpu_last_kernel_ms.restype = C.c_double
     L.racgpu_last_kernel_ms.argtypes = [vp]
+    L.racgpu_column_sweep.restype = C.c_int
+    L.racgpu_column_sweep.argtypes = [vp, C.POINTER(ChemsolParams), C.c_int64, vp, vp, C.c_int64, vp, vp, vp, C.c_double, vp, vp, vp, vp, C.c_int]
     L.racgpu_set_team_threshold.restype = C.c_int
     L.racgpu_set_team_threshold.argtypes = [vp, C.c_double]
     L.racgpu_last_team_cells.restype = C.c_int64
@@ -326,6 +328,24 @@ class Network:
         """racgpu_calc_cells on device pointers (synchronises the handle's stream between local iterations)."""
         _check(lib().racgpu_calc_cells(self._h, C.byref(params), nlocal_iter, ncell, cells_ptr, y_ptr, t_final_ptr, quality_ptr,
                                        stats_ptr, cell_out_ptr, MEM_DEVICE))
+
+    def column_sweep(self, params, cell_records, y, col_ptr, col_cells, dz, dv_turb=1e5):
+        """racgpu_column_sweep: the cells column by column, each column top down on one team of four waves, the toISM
+        self-shielding slots (H2, H2O, OH) of every record rewritten from the cells above it before it is solved.
+        col_ptr [ncolumn + 1], col_cells [ncell] (cell indices, surface first), dz [ncell] path lengths in cm.
+        Returns dict(cells (updated copy), y, t_final, quality, stats, cell_out)."""
+        cr = np.array(cell_records, dtype=np.float64, copy=True).reshape(-1, NPAR)
+        ncell = cr.shape[0]
+        y = np.array(y, dtype=np.float64, copy=True).reshape(ncell, self.nSpecies)
+        cp = np.ascontiguousarray(col_ptr, dtype=np.int32); cc = np.ascontiguousarray(col_cells, dtype=np.int32)
+        dz = np.ascontiguousarray(dz, dtype=np.float64)
+        if cc.size != ncell or dz.size != ncell:
+            raise ValueError("col_cells and dz must have one entry per cell")
+        tf = np.zeros(ncell); q = np.zeros(ncell, np.int32); st = np.zeros((ncell, NSTAT), np.int64); co = np.zeros((ncell, NOUT))
+        _check(lib().racgpu_column_sweep(self._h, C.byref(params), cp.size - 1, cp.ctypes.data, cc.ctypes.data, ncell, cr.ctypes.data,
+                                         y.ctypes.data, dz.ctypes.data, float(dv_turb), tf.ctypes.data, q.ctypes.data, st.ctypes.data,
+                                         co.ctypes.data, MEM_HOST))
+        return dict(cells=cr, y=y, t_final=tf, quality=q, stats=st, cell_out=co)
 
     def set_cost_hints(self, cost=None):
         """Per-cell expected work (e.g. stats[:, S_NST] of the previous global iteration) for the following

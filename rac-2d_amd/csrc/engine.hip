@@ -114,6 +114,13 @@ struct SolveArgs {
   int slot0;                        // this launch's first workspace slot
   int park_max;                     // k_solve: cells may be parked for a team once the queue is empty and <= park_max waves are left (0: never)
   int *park_list, *park_count;      // slots holding parked cells, and how many
+  // k_solve_columns: the cells column by column, top down; the shielding slots of a record are rewritten from what the cells
+  // above it in its column ended with before the cell is solved (racgpu_column_sweep)
+  const int *col_ptr, *col_cells;   // [ncolumn + 1], [ncell]
+  int ncolumn, i_H2O, i_OH;         // (0-based species, -1 absent)
+  const double *dz;                 // [ncell] path length through the cell towards the surface [cm]
+  double dv_turb;                   // turbulent line width [cm/s] of the H2 self-shielding formula
+  double *cells_rw;                 // = cells
 };
 constexpr int kParkWords = 128;     // doubles reserved per slot for struct Parked (in front of the parked iterate)
 static_assert(sizeof(Parked) <= kParkWords * sizeof(double), "Parked outgrew its slot");
@@ -122,7 +129,11 @@ static_assert(sizeof(Parked) <= kParkWords * sizeof(double), "Parked outgrew its
 // the few cells that would otherwise set the length of the pass on their own; wave 0 runs the integrator exactly as with TEAM =
 // 1, the others wait at a barrier for the parts that are shared out (the factorisation, dev_lu's team mode) -- same arithmetic
 // in the same order per column, same results to the last bit.
-template <int TEAM, bool RESUME>
+// what a column has above the cell being solved: column densities [cm^-2] of H2, H2O, OH (wave 0 of the team)
+struct ColumnAcc { double N_H2, N_H2O, N_OH; };
+static __shared__ volatile ColumnAcc g_col;
+
+template <int TEAM, bool RESUME, bool COLUMN = false>
 RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, const SolveArgs &A, double *lds) {
   const int lane = threadIdx.x & 63, wv = TEAM > 1 ? uniform_i((int)(threadIdx.x >> 6)) : 0;
   const int n = N.nS, nlds = (n + 1) & ~1;
@@ -160,14 +171,40 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
   g_wc.inv_neq = 1.0 / (double)(n + 1);
   if (TEAM > 1 && !RESUME && lane == 0) atomicAdd(W.counter - 1, 1); // k_gate: this workgroup is resident (the team queue's counter is word [2], this is [1])
   const int nparked = RESUME ? gptr(A.park_count)[0] : 0;
+  int kpos = 0, kend = 0, kfirst = 0; // COLUMN: the wave's place in its column's cell list
   for (;;) {
     int cell = 0;
-    if (lane == 0) cell = atomicAdd(W.counter, 1);
-    cell = uniform_i(cell);
+    if (!COLUMN || kpos >= kend) { // the next work item: a cell, a parked cell or a column
+      if (lane == 0) cell = atomicAdd(W.counter, 1);
+      cell = uniform_i(cell);
+    }
     dev_mark(c, 10 + cell);
     int slot = own_slot;
     Parked *pk = nullptr;
-    if (RESUME) {
+    if (COLUMN) {
+      if (kpos >= kend) {
+        if (cell >= A.ncolumn) break;
+        kpos = kfirst = A.col_ptr[cell]; kend = A.col_ptr[cell + 1]; // (never empty: racgpu_column_sweep checks)
+        g_col.N_H2 = 0.0; g_col.N_H2O = 0.0; g_col.N_OH = 0.0;
+      }
+      cell = A.col_cells[kpos];
+      if (kpos > kfirst && lane == 0) {
+        // update_params_above_alt's grid-free part (reference src/disk.f90:1840-1859) towards the surface: H2 by Draine &
+        // Bertoldi 1996 eq. 37 (get_H2_self_shielding, :1887-1897; the 0.035 is a single-precision literal there), H2O and OH
+        // by their Lyman-alpha cross sections (src/sub_global_variables.f90:82-83)
+        double *rec = A.cells_rw + (size_t)cell * RACGPU_NPAR;
+        const double x = g_col.N_H2 / 5e14, b5 = A.dv_turb / 1e5, tmp = sqrt(1.0 + x);
+        const double den = 1.0 + x / b5;
+        rec[RACGPU_P_FSS_ISM_H2] = fmin(1.0, 0.965 / (den * den) + (double)0.035f / tmp * exp(-8.5e-4 * tmp));
+        rec[RACGPU_P_FSS_ISM_H2O] = fmin(1.0, exp(-(g_col.N_H2O * 1.2e-17)));
+        rec[RACGPU_P_FSS_ISM_OH] = fmin(1.0, exp(-(g_col.N_OH * 1.8e-18)));
+      }
+      ++kpos;
+      __threadfence(); // the record as every lane (and the rate coefficients below) must see it
+      dev_rates(N, P, A.cells + (size_t)cell * RACGPU_NPAR, W.rates + (size_t)cell * N.nR, lane,
+                A.cell_out ? A.cell_out + (size_t)cell * RACGPU_NOUT + RACGPU_O_R_H2_FORM : nullptr);
+      __threadfence();
+    } else if (RESUME) {
       if (cell >= nparked) break;
       slot = A.park_list[cell];
       bind(slot);
@@ -255,6 +292,16 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
         s[RACGPU_S_ISAV] = R.isav; s[RACGPU_S_NITER] = 1; s[RACGPU_S_NREC] = nrec; s[19] = 0;
       }
     }
+    if (COLUMN) { // what this cell adds to the columns above the next one: its hand-off abundances (as the caller now has them)
+      __threadfence();
+      if (lane == 0) {
+        const double w = cp[RACGPU_P_NGAS] * A.dz[cell];
+        const double *yc = A.yio + (size_t)cell * n;
+        if (N.i_H2 >= 0) g_col.N_H2 = g_col.N_H2 + w * yc[N.i_H2];
+        if (A.i_H2O >= 0) g_col.N_H2O = g_col.N_H2O + w * yc[A.i_H2O];
+        if (A.i_OH >= 0) g_col.N_OH = g_col.N_OH + w * yc[A.i_OH];
+      }
+    }
     dev_mark(c, 6);
   }
   dev_mark(c, 7);
@@ -270,6 +317,11 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
 __global__ __launch_bounds__(64 * kTeam) void k_solve_team(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
   extern __shared__ double lds[];
   solve_body<kTeam, false>(*Np, *Pp, W, A, lds);
+}
+// columns of cells in dependency order, one team per column at a time (racgpu_column_sweep)
+__global__ __launch_bounds__(64 * kTeam) void k_solve_columns(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
+  extern __shared__ double lds[];
+  solve_body<kTeam, false, true>(*Np, *Pp, W, A, lds);
 }
 // the cells k_solve parked, each taken up by a team in the workspace slot it was parked in
 __global__ __launch_bounds__(64 * kTeam) void k_solve_team_resume(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
@@ -1242,6 +1294,54 @@ int racgpu_evol_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t n
         const double *tr = &trace_host[(size_t)i * 8];
         std::fprintf(stderr, "[racgpu trace] call %3d tn=%.6e h=%.6e hu=%.6e nq=%g kflag=%g nst=%g nfe=%g nje/nlu=%g\n", i, tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6], tr[7]);
       }
+    }
+  });
+}
+
+int racgpu_column_sweep(racgpu_network *h, const racgpu_params *p, int64_t ncolumn, const int32_t *col_ptr, const int32_t *col_cells,
+                        int64_t ncell, double *cells, double *y, const double *dz, double dv_turb, double *t_final, int32_t *quality,
+                        int64_t *stats, double *cell_out, int mem) {
+  if (!h) return fail("null network");
+  if (ncolumn <= 0 || ncell <= 0) return 0;
+  if (ncell > 0x7fffffffLL) return fail("ncell exceeds 2^31-1");
+  if (!cells || !y || !col_ptr || !col_cells || !dz) return fail("cells, y, col_ptr, col_cells and dz must not be null");
+  if (!(dv_turb > 0.0)) return fail("dv_turb must be positive");
+  return guarded([&] {
+    h->upload();
+    DevParams P = to_dev(p);
+    push_params(h, P);
+    const size_t nS = h->dn.nS;
+    DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, mem, true), dy(y, ncell * nS * 8, mem, true), dd(dz, ncell * 8, mem, true),
+        dp(col_ptr, (ncolumn + 1) * 4, mem, true), dl(col_cells, ncell * 4, mem, true), dt(t_final, ncell * 8, mem, false),
+        dq(quality, ncell * 4, mem, false), ds(stats, ncell * RACGPU_NSTAT * 8, mem, false),
+        dout(cell_out, (size_t)ncell * RACGPU_NOUT * 8, mem, true);
+    if (mem == RACGPU_MEM_HOST) { // (device buffers are the caller's responsibility)
+      if (col_ptr[0] != 0 || col_ptr[ncolumn] != ncell) throw std::runtime_error("column sweep: col_ptr must run from 0 to ncell");
+      for (int64_t c = 0; c < ncolumn; ++c) if (col_ptr[c + 1] <= col_ptr[c]) throw std::runtime_error("column sweep: empty column");
+      for (int64_t i = 0; i < ncell; ++i) if (col_cells[i] < 0 || col_cells[i] >= ncell) throw std::runtime_error("column sweep: cell index out of range");
+    }
+    h->ws.trace = nullptr; h->ws.marker = nullptr;
+    const long grid = std::min<long>(ncolumn, 2L * h->cu_count); // two teams per CU by registers
+    h->ensure_workspace(grid, (long)ncell);
+    HIP_OK(hipMemsetAsync(h->ws.counter, 0, 8 * sizeof(int), h->stream));
+    HIP_OK(hipMemsetAsync(h->parked_host, 0, sizeof(int), h->stream));
+    h->last_team_cells = ncell;
+    HIP_OK(hipEventRecord(h->ev0, h->stream));
+    SolveArgs A{};
+    A.ncell = (int)ncell; A.flags = 0; A.cells = (const double *)dc.d; A.cells_rw = (double *)dc.d; A.yio = (double *)dy.d;
+    A.t_final = (double *)dt.d; A.quality = (int *)dq.d; A.stats = (long long *)ds.d; A.cell_out = (double *)dout.d;
+    A.col_ptr = (const int *)dp.d; A.col_cells = (const int *)dl.d; A.ncolumn = (int)ncolumn; A.dz = (const double *)dd.d; A.dv_turb = dv_turb;
+    auto find = [&](const char *nm) { for (int i = 0; i < h->net.nS; ++i) if (h->net.names[i] == nm) return i; return -1; };
+    A.i_H2O = find("H2O"); A.i_OH = find("OH");
+    DevWork Wc = h->ws;
+    Wc.counter = h->ws.counter + 6;
+    hipLaunchKernelGGL(k_solve_columns, dim3((unsigned)grid), dim3(64 * kTeam), lds_bytes_team(h->dn), h->stream, h->dn_dev, h->dp_dev, Wc, A);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    if (mem == RACGPU_MEM_HOST) {
+      HIP_OK(hipStreamSynchronize(h->stream));
+      dc.copy_out(); dy.copy_out(); dt.copy_out(); dq.copy_out(); ds.copy_out(); dout.copy_out();
     }
   });
 }

@@ -15,7 +15,7 @@ module racgpu
   public :: racgpu_network_load, racgpu_network_destroy, racgpu_network_dims, racgpu_species_name, &
             racgpu_species_index, racgpu_load_initial_abundances, racgpu_params_default, racgpu_n_record, &
             racgpu_set_tolerances, racgpu_init_abundances, racgpu_set_device, racgpu_device_count, &
-            racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_rectify_abundances, &
+            racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_column_sweep, racgpu_rectify_abundances, &
             racgpu_set_cost_hints, racgpu_set_team_threshold, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
   public :: racgpu_error_string, chemsol_to_c, c_string
 
@@ -191,6 +191,24 @@ module racgpu
       type(c_ptr), value :: h
       real(c_double), dimension(*), intent(in) :: cost
       integer(c_int64_t), value :: ncell
+      integer(c_int) :: rc
+    end function
+    ! the sweep in dependency order for grids whose cells form columns (include/racgpu.h): columns top down, the toISM self-shielding
+    ! slots of H2, H2O and OH rewritten on the device from the cells above; col_ptr/col_cells are 0-based
+    function racgpu_column_sweep(h, p, ncolumn, col_ptr, col_cells, ncell, cells, y, dz, dv_turb, t_final, quality, stats, &
+                                 cell_out, mem) bind(c, name='racgpu_column_sweep') result(rc)
+      import :: c_ptr, c_int64_t, c_int32_t, c_double, c_int, racgpu_params
+      type(c_ptr), value :: h
+      type(racgpu_params), intent(in) :: p
+      integer(c_int64_t), value :: ncolumn, ncell
+      integer(c_int32_t), dimension(*), intent(in) :: col_ptr, col_cells
+      real(c_double), dimension(*), intent(inout) :: cells, y
+      real(c_double), dimension(*), intent(in) :: dz
+      real(c_double), value :: dv_turb
+      real(c_double), dimension(*), intent(out) :: t_final, cell_out
+      integer(c_int32_t), dimension(*), intent(out) :: quality
+      integer(c_int64_t), dimension(*), intent(out) :: stats
+      integer(c_int), value :: mem
       integer(c_int) :: rc
     end function
     ! cells expected to cost more than frac x (sum of the hints / wave slots) get a team of four waves (default 0.5; <= 0 never;

@@ -134,3 +134,51 @@ def test_layer_sweep_on_a_small_grid_feeds_shielding_downwards(racgpu):
     top = layer == 0
     np.testing.assert_array_equal(out["y"][top], jacobi["y"][top])     # the surface layer has nothing above it
     assert not np.array_equal(out["y"][~top], jacobi["y"][~top])       # below, the records differ
+
+
+@pytest.mark.gpu
+def test_column_sweep_on_the_device_is_the_layer_sweep(racgpu):
+    """racgpu_column_sweep: every column top down on one team, the record update on the device.  Against the host-driven
+    layer-by-layer sweep with the same update in numpy: the shielding factors agree to rounding (two libms), the end states to
+    the integrator's noise floor at RTOL 1e-4 and mostly far below it; counters of the surface layer, whose
+    records nothing touches, are identical."""
+    net = racgpu.Network(os.path.join(ROOT, "data", "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat"))
+    y0 = net.load_initial_abundances(os.path.join(ROOT, "data", "ini_abund_waterice_loMetal.dat"))
+    ncol, nz = 8, 6
+    grid = racgpu.cells.andrews_grid(ncol=ncol, nz=nz)
+    ncell = grid.shape[0]
+    column = np.repeat(np.arange(ncol), nz); layer = (nz - 1) - np.tile(np.arange(nz), ncol)
+    dz = np.linspace(0.5e13, 2e13, ncell)
+    p = racgpu.default_params(); p.t_max = 1e3
+    grid[:, racgpu.cells.P_TMAX] = 0.0
+    iH2, iH2O, iOH = (net.species_index(nm) - 1 for nm in ("H2", "H2O", "OH"))
+    C = racgpu.cells
+    dv = 1.3e5
+
+    def update(k, idx, cells_, y_done, done):
+        n = np.zeros(ncell)
+        for sp, slot, f in ((iH2, C.P_FSS_ISM_H2, lambda N: C.h2_self_shielding(N, dv)),
+                            (iH2O, C.P_FSS_ISM_H2O, lambda N: C.lya_self_shielding(N, C.LYA_CROSS_H2O)),
+                            (iOH, C.P_FSS_ISM_OH, lambda N: C.lya_self_shielding(N, C.LYA_CROSS_OH))):
+            n[:] = 0.0
+            n[done] = cells_[done, C.P_NGAS] * y_done[done, sp]
+            cells_[idx, slot] = f(C.column_density_above(n, dz, column, layer)[idx])
+
+    cells_h = grid.copy()
+    host = racgpu.sweep.solve_by_layers(lambda cb, yb: net.evol_solve_batch(p, cb, yb), cells_h, net.init_abundances(y0, grid), layer, update)
+    col_cells = np.concatenate([np.nonzero(column == c)[0][np.argsort(layer[column == c])] for c in range(ncol)])
+    col_ptr = np.arange(ncol + 1) * nz
+    dev = net.column_sweep(p, grid, net.init_abundances(y0, grid), col_ptr, col_cells, dz, dv_turb=dv)
+    for slot in (C.P_FSS_ISM_H2, C.P_FSS_ISM_H2O, C.P_FSS_ISM_OH):
+        np.testing.assert_allclose(dev["cells"][:, slot], cells_h[:, slot], rtol=1e-6)  # (their inputs are end states: see below)
+    untouched = [k for k in range(racgpu.NPAR) if k not in (C.P_FSS_ISM_H2, C.P_FSS_ISM_H2O, C.P_FSS_ISM_OH)]
+    np.testing.assert_array_equal(dev["cells"][:, untouched], grid[:, untouched])
+    top = layer == 0
+    np.testing.assert_array_equal(dev["y"][top], host["y"][top])
+    np.testing.assert_array_equal(dev["stats"][top, :8], host["stats"][top, :8])
+    big = host["y"] >= 1e-6
+    rel = np.abs(dev["y"] / np.where(big, host["y"], 1.0) - 1.0)[big]
+    # a last-bit difference in a shielding factor (device libm against numpy) moves a cell's end state within the RTOL 1e-4 noise
+    # floor of DESIGN.md section 2 (1e-5 ... 1e-3); most cells do not notice
+    assert np.median(rel) < 1e-9 and np.quantile(rel, 0.9) < 1e-5 and rel.max() < 3e-3, (rel.max(), np.quantile(rel, 0.9), np.median(rel))
+    assert (dev["quality"] == 0).all() and (dev["t_final"] == 1e3).all()
