@@ -32,12 +32,13 @@ def test_k_solve_has_no_scratch_and_fits_three_waves_per_simd():
         if m and cur:
             kernels[cur][m.group(1).strip()] = m.group(2)
     ks = {k: v for k, v in kernels.items() if "k_solve" in k}
-    assert len(ks) == 3, (list(kernels), text[-2000:])  # k_solve (one wave per cell), k_solve_team and k_solve_team_resume (four)
+    # k_solve (one wave per cell); k_solve_team, k_solve_team_resume and k_solve_columns (four)
+    assert len(ks) == 4, (list(kernels), text[-2000:])
     for name, k in ks.items():
         assert int(k["ScratchSize"]) == 0, (name, k)           # never: see the module docstring
         assert int(k["AGPRs"]) == 0, (name, k)                 # AGPR spills mean the 256 VGPRs ran out
         assert int(k["VGPRs Spill"]) == 0, (name, k)
-        if "resume" in name:  # runs after k_solve, on an otherwise idle chip: one team per CU
+        if "resume" in name or "columns" in name:  # run on an otherwise idle chip: two teams per CU
             assert int(k["VGPRs"]) <= 256, (name, k)
             continue
         if "team" in name:    # one wave of a team next to two single ones on a SIMD: 176 + 2 * 168 = 512 registers
