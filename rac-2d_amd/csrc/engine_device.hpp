@@ -266,7 +266,10 @@ RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double ns
   // the three common flux forms are selected without branching; only the surface-layer forms (62, 75) branch.
   const rsrc_t bW0 = mkbuf(N.rhs_w0), bW1 = mkbuf(N.rhs_w1), bW2 = mkbuf(N.rhs_w2), bK = mkbuf(rates);
   const int l8 = lane * 8, spare0 = 2 * ((N.nS + 1) & ~1);
-  constexpr int D = 3;
+#ifndef RG_RHS_DEPTH
+#define RG_RHS_DEPTH 3
+#endif
+  constexpr int D = RG_RHS_DEPTH;
   uint64_t w0[D], w1[D], w2[D];
   double kk[D];
 #pragma unroll

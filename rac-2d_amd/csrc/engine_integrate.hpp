@@ -16,6 +16,10 @@
 
 namespace racgpu {
 
+#ifndef RG_VEC_TRIP
+#define RG_VEC_TRIP 8 // blocks of 64 per trip of the integrator's vector loops (vec_trips)
+#endif
+
 struct CellCtx {
   double *y, *savf, *wx;                                       // LDS, nS doubles each: iterate, f(y), linear-solver work vector
   double *acor, *ewt;                                          // HBM, npad each: accumulated correction, inverse error weights (elementwise use only)
@@ -67,7 +71,7 @@ template <typename V>
 RG_DEV double dev_vnorm(const CellCtx &c, V v) { // DVNORM over NEQ = nS+1 entries, the T entry being zero
   double s = 0.0;
   const rsrc_t bE = mkbuf(c.ewt);
-  vec_trips<4, double>(c.n, c.npad, [&](int i0) { return bload_f64(bE, c.lane * 8, i0 * 8); },
+  vec_trips<RG_VEC_TRIP, double>(c.n, c.npad, [&](int i0) { return bload_f64(bE, c.lane * 8, i0 * 8); },
                        [&](int i0, double e) { const int i = i0 + c.lane; if (i < c.n) { const double q = v(i) * e; s += q * q; } });
   return sqrt(wave_sum(s) * g_wc.inv_neq);
 }
@@ -112,7 +116,7 @@ RG_DEV void dev_rescale(const CellCtx &c, Lsodes &s, double rh, bool apply_hmin)
   for (int j = 2; j <= s.l; ++j) {
     r = r * rh;
     const int co = col_off(c, j - 1);
-    vec_trips<4, double>(c.n, c.npad, [&](int i0) { return bload_f64(bY, l8, co + i0 * 8); }, [&](int i0, double v) { bstore_f64(bY, l8, co + i0 * 8, v * r); });
+    vec_trips<RG_VEC_TRIP, double>(c.n, c.npad, [&](int i0) { return bload_f64(bY, l8, co + i0 * 8); }, [&](int i0, double v) { bstore_f64(bY, l8, co + i0 * 8, v * r); });
   }
   s.h = s.h * rh; s.rc = s.rc * rh; s.ialth = s.l;
 }
@@ -232,7 +236,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     bool converged = false;
     for (int pass = 0; pass < 4; ++pass) { // label 220: re-entered after a P refresh (at most twice: rescaled P, then fresh J)
       m = 0;
-      vec_trips<4, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
+      vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
       { const long long t0 = dev_clock(); dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
       dev_mark(c, 2200 + pass);
       if (s.ipup > 0) {
@@ -244,14 +248,14 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bA, l8, i0 * 8, 0.0);
       bool fail410 = false;
       for (;;) {
-        vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
+        vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                          [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) c.y[i] = s.h * c.savf[i] - (v.a + v.b); });
         dev_mark(c, 2400 + m);
         { const long long t0 = dev_clock(); dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane); cyc_add(CYC_SOLVE, dev_clock() - t0); }
         dev_mark(c, 2500 + m);
         del = dev_vnorm(c, [&](int i) { return c.y[i]; });
         const double el1 = P.elco[s.nq][1];
-        vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
+        vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                          [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) { const double a = v.b + c.y[i]; bstore_f64(bA, l8, i0 * 8, a); c.y[i] = v.a + el1 * a; } });
         if (m != 0) s.crate = fmax(0.2 * s.crate, del / delp);
         const double dcon = del * fmin(1.0, 1.5 * s.crate) / (P.tesco[s.nq][2] * s.conit);
@@ -281,7 +285,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     if (m == 0) dsm = del / P.tesco[s.nq][2];
     else {
       double q = 0.0;
-      vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bA, l8, i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
+      vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bA, l8, i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
                        [&](int i0, D2 v) { const double w = v.a * v.b; if (i0 + lane < n) q += w * w; });
       dsm = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][2];
     }
@@ -297,7 +301,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (s.kflag == -10) { s.kflag = -1; break; }
         rh = 0.1;
         s.h = s.h * rh;
-        vec_trips<4, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
+        vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
         dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe++;
         for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, 1) + i0 * 8, s.h * c.savf[i]); }
         s.ipup = 1; s.ialth = 5;
@@ -330,7 +334,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       if (s.ialth == 0) { // label 520
         rhup = 0.0;
         if (s.l != s.lmax) {
-          vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
+          vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                            [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) c.savf[i] = v.b - v.a; });
           const double dup = dev_vnorm(c, [&](int i) { return c.savf[i]; }) / P.tesco[s.nq][3];
           const double exup = 1.0 / (s.l + 1);
@@ -351,7 +355,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       double rhdn = 0.0;
       if (s.nq != 1) {
         double q = 0.0;
-        vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
+        vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
                          [&](int i0, D2 v) { const double w = v.a * v.b; if (i0 + lane < n) q += w * w; });
         const double ddn = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][1];
         const double exdn = 1.0 / s.nq;
@@ -383,7 +387,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
 
 done700: {
     const double r = 1.0 / P.tesco[s.nqu][2];
-    vec_trips<4, double>(n, c.npad, [&](int i0) { return bload_f64(bA, l8, i0 * 8); }, [&](int i0, double v) { bstore_f64(bA, l8, i0 * 8, v * r); });
+    vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bA, l8, i0 * 8); }, [&](int i0, double v) { bstore_f64(bA, l8, i0 * 8, v * r); });
   }
   s.hold = s.h; s.jstart = 1;
   return s.kflag;
@@ -413,7 +417,7 @@ RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some w
   bool bad = false;
   const rsrc_t bY = mkbuf(c.yh), bR = mkbuf(c.rtol), bA = mkbuf(c.atol), bE = mkbuf(c.ewt);
   const int l8 = c.lane * 8;
-  vec_trips<4, D3>(c.n, c.npad, [&](int i0) { return D3{bload_f64(bR, l8, i0 * 8), bload_f64(bY, l8, i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
+  vec_trips<RG_VEC_TRIP, D3>(c.n, c.npad, [&](int i0) { return D3{bload_f64(bR, l8, i0 * 8), bload_f64(bY, l8, i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                    [&](int i0, D3 v) {
                      const double e = v.a * fabs(v.b) + v.c;
                      if (i0 + c.lane < c.n && e <= 0.0) bad = true;
@@ -426,7 +430,7 @@ RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some w
 
 RG_DEV void dev_finish(const CellCtx &c, const Lsodes &s, double &t) { // label 580 / 400
   const rsrc_t bY = mkbuf(c.yh);
-  vec_trips<4, double>(c.n, c.npad, [&](int i0) { return bload_f64(bY, c.lane * 8, i0 * 8); }, [&](int i0, double v) { if (i0 + c.lane < c.n) c.y[i0 + c.lane] = v; });
+  vec_trips<RG_VEC_TRIP, double>(c.n, c.npad, [&](int i0) { return bload_f64(bY, c.lane * 8, i0 * 8); }, [&](int i0, double v) { if (i0 + c.lane < c.n) c.y[i0 + c.lane] = v; });
   t = s.tn;
 }
 
@@ -560,7 +564,7 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
     first = false;
     {
       double q = 0.0;
-      vec_trips<4, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
+      vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
                        [&](int i0, D2 w) { const double v = w.a * w.b; if (i0 + lane < n) q += v * v; });
       const double Tg = g_wc.Tgas, vT = Tg / (g_wc.rT * fabs(Tg) + g_wc.aT);
       const double tolsf = u * sqrt((wave_sum(q) + vT * vT) * g_wc.inv_neq);
