@@ -31,7 +31,7 @@ constexpr int kSweepDepth = RG_SWEEP_DEPTH; // chunks of a triangular-solve stre
 #define RG_TEAM 4
 #endif
 constexpr int kTeam = RG_TEAM; // waves of a team (k_solve_team: the cells that would otherwise set the length of a pass)
-constexpr int kLuDepth = RG_LU_DEPTH; // L columns in flight per wave in the LDS pivot loop; descriptor slices are padded to a multiple of it
+constexpr int kLuDepth = RG_LU_DEPTH; // L columns in flight per wave in the LDS pivot loop
 
 struct DevNet {
   int nS, nR, npad;          // npad = nS rounded up to 64
@@ -71,7 +71,7 @@ struct DevNet {
   // LU pivot descriptors, per column j one slice [d0, d1): for every pivot k < ns of the column, in U storage order, one word
   // for (a piece of at most 64 rows of) L column k, [start, start+len) in the storage: bits 0-15 k; 16-25 8*len; 30 "reload w[k]"
   // (the pivot opens a new level within column j, or is the first of a fetch of 60); 32-52 2*start; 53-61 8*(len-1) (0 for
-  // len 0) -- everything the pivot loop needs as byte offsets.  Slices are padded with null descriptors (all zero).
+  // len 0) -- everything the pivot loop needs as byte offsets.
   const unsigned long long *Udesc;
   const LuCol *lucol;        // [nwork+2] the LU's work list (engine.hip, upload): columns with pivots, then the trailing block
   int nwork_sparse, nwork;   // work items with j < ns / in all

@@ -662,7 +662,6 @@ void racgpu_network::upload() {
                          ((start * 2) << 32) | (((rows > 0 ? rows - 1 : 0) * 8) << 53));
           }
         }
-        while (ud.size() % kLuDepth) ud.push_back(0ull);
         c.d1 = (int)ud.size();
         lc.push_back(c);
         if (j < S.ns) ++nwork_sparse;

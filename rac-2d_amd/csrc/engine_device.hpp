@@ -475,7 +475,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     constexpr int D = kLuDepth;
     constexpr int CH = 64 / D * D; // descriptors per fetch: one per lane, a multiple of D
     for (int base = cur.d0; base < cur.d1; base += CH) {
-      const int nk = min(CH, cur.d1 - base); // a multiple of D (the slices are padded with null descriptors)
+      const int nk = min(CH, cur.d1 - base), nmain = nk / D * D; // whole turns of the register sets, then up to D - 1 single pivots
       const unsigned long long dq = (base == cur.d0) ? dq0 : bload_u64(bUdesc, l8, base * 8);
       const int dlo = (int)(dq & 0xffffffffull), dhi = (int)(dq >> 32);
       const int myk = dlo & 0xffff;
@@ -496,24 +496,30 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   }
 #pragma unroll
       for (int s = 0; s < D - 1; ++s) { RG_LU_ISSUE(s, s) __builtin_amdgcn_sched_barrier(0); } // keep the issue order: data returns in order
-      for (int t = 0; t < nk; t += D) {
+#define RG_LU_PIVOT(s, t_)                                                                                        \
+  {                                                                                                               \
+    RG_LU_ISSUE(((s) + D - 1) % D, (t_) + (s) + D - 1)                                                             \
+    const int tt = (t_) + (s);                                                                                     \
+    if (ds[s] & (1 << 30)) { /* w[k] of this level's pivots is final now */                                        \
+      lds_order();                                                                                                 \
+      tvv = wv[myk];                                                                                               \
+      asm volatile("" : "+v"(tvv)); /* take the LDS wait here, so that pivots which do not open a level never wait on LDS */ \
+    }                                                                                                              \
+    union { double d; int w[2]; } src, tv;                                                                         \
+    src.d = tvv;                                                                                                   \
+    tv.w[0] = __builtin_amdgcn_readlane(src.w[0], tt);                                                             \
+    tv.w[1] = __builtin_amdgcn_readlane(src.w[1], tt);                                                             \
+    /* no exec-masked branch: lanes past the end of the L column add (a finite product of neighbouring entries) to a slot of their own */ \
+    atomicAdd(l8 < ((ds[s] >> 16) & 0x3ff) ? &wv[i[s]] : &dmy[lane], -(l[s] * tv.d));                              \
+  }
+      for (int t = 0; t < nmain; t += D) {
 #pragma unroll
-        for (int s = 0; s < D; ++s) {
-          RG_LU_ISSUE((s + D - 1) % D, t + s + D - 1)
-          const int tt = t + s;
-          if (ds[s] & (1 << 30)) { // w[k] of this level's pivots is final now
-            lds_order();
-            tvv = wv[myk];
-            asm volatile("" : "+v"(tvv)); // take the LDS wait here, so that pivots which do not open a level never wait on LDS
-          }
-          union { double d; int w[2]; } src, tv;
-          src.d = tvv;
-          tv.w[0] = __builtin_amdgcn_readlane(src.w[0], tt);
-          tv.w[1] = __builtin_amdgcn_readlane(src.w[1], tt);
-          // no exec-masked branch: lanes past the end of the L column add (a finite product of neighbouring entries) to a slot of their own
-          atomicAdd(l8 < ((ds[s] >> 16) & 0x3ff) ? &wv[i[s]] : &dmy[lane], -(l[s] * tv.d));
-        }
+        for (int s = 0; s < D; ++s) RG_LU_PIVOT(s, t)
       }
+#pragma unroll
+      for (int s = 0; s < D - 1; ++s) // the rest of the slice (padding it to the depth instead made every tenth pivot a null one)
+        if (s < nk - nmain) RG_LU_PIVOT(s, nmain)
+#undef RG_LU_PIVOT
 #undef RG_LU_ISSUE
     }
     RG_TICK(c_rect)
