@@ -101,6 +101,32 @@ def test_four_waves_on_a_cell_give_the_bits_of_one(racgpu, setup):
         net.set_cost_hints(None)
 
 
+@pytest.mark.parametrize("network", ["rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "rate06_withgrain_lowH2Bind_hiOBind_lowCObind.dat",
+                                     "rate12_withGrain_lowH2Bind_hiObind.dat"])
+def test_teams_on_every_network(racgpu, network):
+    """The team tables (level lists of the sparse columns, Jacobian segments, trailing rounds) are built per network: on each of
+    the other three networks, cells in teams from the start and cells handed over end with the bits of one wave per cell."""
+    import os
+    from conftest import ROOT
+    net = racgpu.Network(os.path.join(ROOT, "data", network))
+    y0 = net.load_initial_abundances(os.path.join(ROOT, "data", "ini_abund_waterice_loMetal.dat"))
+    p = racgpu.default_params(); p.t_max = 1e2
+    cells = racgpu.cells.synth_batch(6, seed=17)
+    try:
+        net.set_team_threshold(-1.0)
+        base = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells))
+        for frac, hinted in ((1e-9, True), (0.5, False)):
+            net.set_team_threshold(frac)
+            net.set_cost_hints(np.ones(6) if hinted else None)
+            out = net.evol_solve_batch(p, cells, net.init_abundances(y0, cells))
+            assert net.last_team_cells() == (6 if hinted else 0) and (hinted or net.last_parked_cells() > 0)
+            np.testing.assert_array_equal(out["y"], base["y"])
+            np.testing.assert_array_equal(out["stats"][:, :8], base["stats"][:, :8])
+    finally:
+        net.set_team_threshold(0.5)
+        net.set_cost_hints(None)
+
+
 def test_step_budget_stops_a_cell_like_a_premature_finish(racgpu, setup):
     net, y0 = setup
     p = racgpu.default_params(); p.max_steps_per_cell = 100
