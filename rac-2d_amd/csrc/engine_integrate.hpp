@@ -122,7 +122,7 @@ RG_DEV void dev_rescale(const CellCtx &c, Lsodes &s, double rh, bool apply_hmin)
 }
 
 // YH <- YH * Pascal (forward) or its inverse; DSTODE :865-874, :956-962
-RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward) {
+RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward, bool to_y = false) { // to_y: the new first column goes to y (LDS) as well
   const int nq = s.nq;
   const rsrc_t bY = mkbuf(c.yh);
   const int l8 = c.lane * 8;
@@ -144,6 +144,7 @@ RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward) {
 #pragma unroll
       for (int j = 0; j < kMaxord; ++j)
         if (j < nq) bstore_f64(bY, l8, col_off(c, j) + i0 * 8, d.v[j]);
+      if (to_y && i0 + c.lane < c.n) c.y[i0 + c.lane] = d.v[0];
     });
 }
 
@@ -230,13 +231,14 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     if (s.nst >= s.nslp + kMsbp) s.ipup = 1;
     s.tn = s.tn + s.h;
     dev_mark(c, 2000 + guard);
-    dev_pascal(c, s, true);
+    dev_pascal(c, s, true, true); // (the prediction is the corrector's first iterate: one pass over the array instead of two)
     dev_mark(c, 2100 + guard);
 
     bool converged = false;
     for (int pass = 0; pass < 4; ++pass) { // label 220: re-entered after a P refresh (at most twice: rescaled P, then fresh J)
       m = 0;
-      vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
+      if (pass > 0) vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
+      else wave_sync();
       { const long long t0 = dev_clock(); dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
       dev_mark(c, 2200 + pass);
       if (s.ipup > 0) {
@@ -414,6 +416,8 @@ RG_DEV void dev_intdy0(const CellCtx &c, const Lsodes &s, double t) { // y <- in
 }
 
 RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some weight is <= 0
+  // (folding the driver's TOLSF sum, which reads the same two vectors next, into this pass costs two registers kernel-wide and
+  // with them the third wave per SIMD: tried, not kept)
   bool bad = false;
   const rsrc_t bY = mkbuf(c.yh), bR = mkbuf(c.rtol), bA = mkbuf(c.atol), bE = mkbuf(c.ewt);
   const int l8 = c.lane * 8;
