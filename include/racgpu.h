@@ -195,12 +195,6 @@ int racgpu_calc_cells(racgpu_network *, const racgpu_params *, int32_t nlocal_it
                       double *t_final, int32_t *quality, int64_t *stats, double *cell_out, int mem);
 /* rectify_abundances (src/chemistry.f90:2170-2201) on host arrays: y[c, E-] += sum(charge * y[c, :]) */
 int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
-/* Scheduling hint for the following racgpu_solve_batch calls (an extension: the reference has no counterpart; its
- * cell loop, src/disk.f90:864-1010, takes cells in grid order).  cost[ncell] (host memory) is any per-cell measure
- * of expected work, e.g. the step count RACGPU_S_NST or the cycle count RACGPU_S_CYC_TOTAL the same cell needed in
- * the previous global iteration of the disk model; waves then take cells in order of decreasing cost, so the few
- * cells that need many times the median work start first instead of last.  Results do not depend on the order.
- * The hint applies while ncell matches; cost == NULL or ncell == 0 clears it. */
 /* The caller's sweep in dependency order, for grids whose cells form columns (reference: a cell is solved once the cells above
  * it are done, update_calculating_cells src/disk.f90:1937, because update_params_above_alt :1823-1883 puts integrals over their
  * end states into its record).  Column c holds cells col_cells[col_ptr[c] .. col_ptr[c+1]) from the surface downwards; every
@@ -212,12 +206,18 @@ int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
 int racgpu_column_sweep(racgpu_network *, const racgpu_params *, int64_t ncolumn, const int32_t *col_ptr, const int32_t *col_cells,
                         int64_t ncell, double *cells, double *y, const double *dz, double dv_turb, double *t_final, int32_t *quality,
                         int64_t *stats, double *cell_out, int mem);
+/* Scheduling hint for the following racgpu_solve_batch calls (an extension: the reference has no counterpart; its
+ * cell loop, src/disk.f90:864-1010, takes cells in grid order).  cost[ncell] (host memory) is any per-cell measure
+ * of expected work, e.g. the step count RACGPU_S_NST or the cycle count RACGPU_S_CYC_TOTAL the same cell needed in
+ * the previous global iteration of the disk model; waves then take cells in order of decreasing cost, so the few
+ * cells that need many times the median work start first instead of last.  Results do not depend on the order.
+ * The hint applies while ncell matches; cost == NULL or ncell == 0 clears it. */
 int racgpu_set_cost_hints(racgpu_network *, const double *cost, int64_t ncell);
 /* With cost hints in place, a cell whose expected cost exceeds frac x (sum of the costs / wave slots of the GPU) -- a cell that
  * would take that share of the pass's ideal length all by itself -- is solved by a team of four waves (at most one team per CU),
  * started ahead of the rest.  Same arithmetic in the same order: results do not depend on it.  Default 0.5; frac <= 0: never.
  * Independently of hints, the cells still being integrated when the queue is empty and at most two waves per CU are left are handed
- * over to teams between two output times (frac < 0 switches that off as well). */
+ * over to teams between two integrator steps (frac < 0 switches that off as well). */
 int racgpu_set_team_threshold(racgpu_network *, double frac);
 /* cells the last solve pass gave to teams */
 int64_t racgpu_last_team_cells(const racgpu_network *);
