@@ -200,9 +200,14 @@ int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
  * end states into its record).  Column c holds cells col_cells[col_ptr[c] .. col_ptr[c+1]) from the surface downwards; every
  * column is solved top down by one team of four waves, columns side by side.  Before a cell is solved, the toISM self-shielding
  * slots of its record are rewritten from the column densities N = sum n_gas X dz of the cells above it: H2 by
- * get_H2_self_shielding(N_H2, dv_turb) (:1887-1897), H2O and OH by exp(-N sigma_Lya) (:1847-1859), all capped at 1; the CO slot
- * and the toStar slots stay as given (they need the reference's tables / ray tracing).  cells is updated in place; everything
+ * get_H2_self_shielding(N_H2, dv_turb) (:1887-1897), H2O and OH by exp(-N sigma_Lya) (:1847-1859), CO by get_12CO_shielding(N_H2,
+ * N_CO) on the table given to racgpu_set_co_shielding_table (without one the CO slot stays as given), all capped at 1; the toStar
+ * slots stay as given (they need ray tracing).  cells is updated in place; everything
  * else as racgpu_evol_solve_batch with t0 = 0 and the handle's default tolerance policy. */
+/* 12CO shielding table for racgpu_column_sweep: f[ncol][nrow] > 0 over ascending log10 column densities logN_12CO[ncol], logN_H2[nrow]
+ * (the layout of the reference's f_12CO(ncol, nrow), src/load_Visser_CO_selfshielding.f90; its own Visser et al. 2009 table is
+ * compiled into it and not shipped here: the caller supplies one).  f == NULL clears it. */
+int racgpu_set_co_shielding_table(racgpu_network *, int32_t nrow, int32_t ncol, const double *logN_H2, const double *logN_12CO, const double *f);
 int racgpu_column_sweep(racgpu_network *, const racgpu_params *, int64_t ncolumn, const int32_t *col_ptr, const int32_t *col_cells,
                         int64_t ncell, double *cells, double *y, const double *dz, double dv_turb, double *t_final, int32_t *quality,
                         int64_t *stats, double *cell_out, int mem);

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "racgpu_species_attrs", "racgpu_species_elements", "racgpu_reaction_rows", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
-    "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_column_sweep", "racgpu_rectify_abundances",
+    "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_column_sweep", "racgpu_set_co_shielding_table", "racgpu_rectify_abundances",
     "racgpu_set_cost_hints", "racgpu_set_team_threshold", "racgpu_last_team_cells", "racgpu_last_parked_cells", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
 ]
 
@@ -115,6 +115,8 @@ def lib():
     L.racgpu_last_kernel_ms.argtypes = [vp]
     L.racgpu_column_sweep.restype = C.c_int
     L.racgpu_column_sweep.argtypes = [vp, C.POINTER(ChemsolParams), C.c_int64, vp, vp, C.c_int64, vp, vp, vp, C.c_double, vp, vp, vp, vp, C.c_int]
+    L.racgpu_set_co_shielding_table.restype = C.c_int
+    L.racgpu_set_co_shielding_table.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.racgpu_set_team_threshold.restype = C.c_int
     L.racgpu_set_team_threshold.argtypes = [vp, C.c_double]
     L.racgpu_last_team_cells.restype = C.c_int64
@@ -328,6 +330,17 @@ class Network:
         """racgpu_calc_cells on device pointers (synchronises the handle's stream between local iterations)."""
         _check(lib().racgpu_calc_cells(self._h, C.byref(params), nlocal_iter, ncell, cells_ptr, y_ptr, t_final_ptr, quality_ptr,
                                        stats_ptr, cell_out_ptr, MEM_DEVICE))
+
+    def set_co_shielding_table(self, table=None):
+        """12CO shielding table for column_sweep: (logN_H2 [nrow], logN_12CO [ncol], f [ncol, nrow]) as cells.co_shielding takes
+        it; None clears it (the CO slot of the records then stays as given)."""
+        if table is None:
+            _check(lib().racgpu_set_co_shielding_table(self._h, 0, 0, None, None, None))
+            return
+        lh, lc, f = (np.ascontiguousarray(a, dtype=np.float64) for a in table)
+        if f.shape != (lc.size, lh.size):
+            raise ValueError("f must be [ncol, nrow]")
+        _check(lib().racgpu_set_co_shielding_table(self._h, lh.size, lc.size, lh.ctypes.data, lc.ctypes.data, f.ctypes.data))
 
     def column_sweep(self, params, cell_records, y, col_ptr, col_cells, dz, dv_turb=1e5):
         """racgpu_column_sweep: the cells column by column, each column top down on one team of four waves, the toISM

@@ -117,7 +117,10 @@ struct SolveArgs {
   // k_solve_columns: the cells column by column, top down; the shielding slots of a record are rewritten from what the cells
   // above it in its column ended with before the cell is solved (racgpu_column_sweep)
   const int *col_ptr, *col_cells;   // [ncolumn + 1], [ncell]
-  int ncolumn, i_H2O, i_OH;         // (0-based species, -1 absent)
+  int ncolumn, i_H2O, i_OH, i_CO;   // (0-based species, -1 absent)
+  // 12CO shielding table of the caller (racgpu_set_co_shielding_table): axes ascending, f[ncol][nrow] with ln f stored; null: the CO
+  // slot of the records stays as given
+  const double *co_logNH2, *co_logNCO, *co_lnf; int co_nrow, co_ncol;
   const double *dz;                 // [ncell] path length through the cell towards the surface [cm]
   double dv_turb;                   // turbulent line width [cm/s] of the H2 self-shielding formula
   double *cells_rw;                 // = cells
@@ -130,7 +133,7 @@ static_assert(sizeof(Parked) <= kParkWords * sizeof(double), "Parked outgrew its
 // 1, the others wait at a barrier for the parts that are shared out (the factorisation, dev_lu's team mode) -- same arithmetic
 // in the same order per column, same results to the last bit.
 // what a column has above the cell being solved: column densities [cm^-2] of H2, H2O, OH (wave 0 of the team)
-struct ColumnAcc { double N_H2, N_H2O, N_OH; };
+struct ColumnAcc { double N_H2, N_H2O, N_OH, N_CO; };
 static __shared__ volatile ColumnAcc g_col;
 
 template <int TEAM, bool RESUME, bool COLUMN = false>
@@ -185,7 +188,7 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
       if (kpos >= kend) {
         if (cell >= A.ncolumn) break;
         kpos = kfirst = A.col_ptr[cell]; kend = A.col_ptr[cell + 1]; // (never empty: racgpu_column_sweep checks)
-        g_col.N_H2 = 0.0; g_col.N_H2O = 0.0; g_col.N_OH = 0.0;
+        g_col.N_H2 = 0.0; g_col.N_H2O = 0.0; g_col.N_OH = 0.0; g_col.N_CO = 0.0;
       }
       cell = A.col_cells[kpos];
       if (kpos > kfirst && lane == 0) {
@@ -198,6 +201,18 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
         rec[RACGPU_P_FSS_ISM_H2] = fmin(1.0, 0.965 / (den * den) + (double)0.035f / tmp * exp(-8.5e-4 * tmp));
         rec[RACGPU_P_FSS_ISM_H2O] = fmin(1.0, exp(-(g_col.N_H2O * 1.2e-17)));
         rec[RACGPU_P_FSS_ISM_OH] = fmin(1.0, exp(-(g_col.N_OH * 1.8e-18)));
+        if (A.co_lnf) { // get_12CO_shielding (reference src/load_Visser_CO_selfshielding.f90:271-309) on the caller's table
+          const double xl = log10(fmax(g_col.N_CO, 1.0)), yl = log10(fmax(g_col.N_H2, 1.0));
+          int i1 = 0, j1 = 0; // the enclosing table cell; the last one beyond the table, the first one below it
+          for (int i = 0; i < A.co_nrow - 1; ++i) if (A.co_logNH2[i] < yl) i1 = i;
+          for (int j = 0; j < A.co_ncol - 1; ++j) if (A.co_logNCO[j] < xl) j1 = j;
+          const double x1 = A.co_logNCO[j1], x2 = A.co_logNCO[j1 + 1], y1 = A.co_logNH2[i1], y2 = A.co_logNH2[i1 + 1];
+          const double z11 = A.co_lnf[(size_t)j1 * A.co_nrow + i1], z12 = A.co_lnf[(size_t)j1 * A.co_nrow + i1 + 1];
+          const double z21 = A.co_lnf[(size_t)(j1 + 1) * A.co_nrow + i1], z22 = A.co_lnf[(size_t)(j1 + 1) * A.co_nrow + i1 + 1];
+          const double k1 = (z12 - z11) / (y2 - y1), k2 = (z22 - z21) / (y2 - y1); // calc_four_point_linear_interpol, src/sub_trivials.f90:803-821
+          const double v = ((k2 - k1) / (x2 - x1) * (xl - x1) + k1) * (yl - y1) + (z21 - z11) / (x2 - x1) * (xl - x1) + z11;
+          rec[RACGPU_P_FSS_ISM_CO] = fmin(1.0, fmax(0.0, exp(v)));
+        }
       }
       ++kpos;
       __threadfence(); // the record as every lane (and the rate coefficients below) must see it
@@ -300,6 +315,7 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
         if (N.i_H2 >= 0) g_col.N_H2 = g_col.N_H2 + w * yc[N.i_H2];
         if (A.i_H2O >= 0) g_col.N_H2O = g_col.N_H2O + w * yc[A.i_H2O];
         if (A.i_OH >= 0) g_col.N_OH = g_col.N_OH + w * yc[A.i_OH];
+        if (A.i_CO >= 0) g_col.N_CO = g_col.N_CO + w * yc[A.i_CO];
       }
     }
     dev_mark(c, 6);
@@ -407,6 +423,7 @@ struct racgpu_network {
   hipStream_t team_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   long last_team_cells = 0;       // cells the last pass solved four waves at a time
   int *parked_host = nullptr;     // pinned: cells the last pass (its last chunk) handed over to teams at its end
+  double *co_logNH2 = nullptr, *co_logNCO = nullptr, *co_lnf = nullptr; int co_nrow = 0, co_ncol = 0; // racgpu_set_co_shielding_table
   bool timed = false;
   int cu_count = 0;
 
@@ -436,6 +453,7 @@ struct racgpu_network {
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (team_stream) (void)hipStreamDestroy(team_stream);
     if (parked_host) (void)hipHostFree(parked_host);
+    for (double *q : {co_logNH2, co_logNCO, co_lnf}) if (q) (void)hipFree(q);
   }
 };
 
@@ -1297,6 +1315,24 @@ int racgpu_evol_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t n
   });
 }
 
+int racgpu_set_co_shielding_table(racgpu_network *h, int32_t nrow, int32_t ncol, const double *logN_H2, const double *logN_12CO, const double *f) {
+  if (!h) return fail("null network");
+  return guarded([&] {
+    require_gpu();
+    for (double **q : {&h->co_logNH2, &h->co_logNCO, &h->co_lnf}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    h->co_nrow = h->co_ncol = 0;
+    if (!f || nrow < 2 || ncol < 2) return; // cleared
+    if (!logN_H2 || !logN_12CO) throw std::runtime_error("CO shielding table: axes missing");
+    for (int i = 1; i < nrow; ++i) if (!(logN_H2[i] > logN_H2[i - 1])) throw std::runtime_error("CO shielding table: logN_H2 must ascend");
+    for (int j = 1; j < ncol; ++j) if (!(logN_12CO[j] > logN_12CO[j - 1])) throw std::runtime_error("CO shielding table: logN_12CO must ascend");
+    std::vector<double> lnf((size_t)nrow * ncol);
+    for (size_t q = 0; q < lnf.size(); ++q) { if (!(f[q] > 0.0)) throw std::runtime_error("CO shielding table: f must be positive"); lnf[q] = std::log(f[q]); }
+    auto put = [&](double **d, const double *src, size_t n) { HIP_OK(hipMalloc((void **)d, n * 8)); HIP_OK(hipMemcpy(*d, src, n * 8, hipMemcpyHostToDevice)); };
+    put(&h->co_logNH2, logN_H2, nrow); put(&h->co_logNCO, logN_12CO, ncol); put(&h->co_lnf, lnf.data(), lnf.size());
+    h->co_nrow = nrow; h->co_ncol = ncol;
+  });
+}
+
 int racgpu_column_sweep(racgpu_network *h, const racgpu_params *p, int64_t ncolumn, const int32_t *col_ptr, const int32_t *col_cells,
                         int64_t ncell, double *cells, double *y, const double *dz, double dv_turb, double *t_final, int32_t *quality,
                         int64_t *stats, double *cell_out, int mem) {
@@ -1331,7 +1367,8 @@ int racgpu_column_sweep(racgpu_network *h, const racgpu_params *p, int64_t ncolu
     A.t_final = (double *)dt.d; A.quality = (int *)dq.d; A.stats = (long long *)ds.d; A.cell_out = (double *)dout.d;
     A.col_ptr = (const int *)dp.d; A.col_cells = (const int *)dl.d; A.ncolumn = (int)ncolumn; A.dz = (const double *)dd.d; A.dv_turb = dv_turb;
     auto find = [&](const char *nm) { for (int i = 0; i < h->net.nS; ++i) if (h->net.names[i] == nm) return i; return -1; };
-    A.i_H2O = find("H2O"); A.i_OH = find("OH");
+    A.i_H2O = find("H2O"); A.i_OH = find("OH"); A.i_CO = find("CO");
+    A.co_logNH2 = h->co_logNH2; A.co_logNCO = h->co_logNCO; A.co_lnf = h->co_lnf; A.co_nrow = h->co_nrow; A.co_ncol = h->co_ncol;
     DevWork Wc = h->ws;
     Wc.counter = h->ws.counter + 6;
     hipLaunchKernelGGL(k_solve_columns, dim3((unsigned)grid), dim3(64 * kTeam), lds_bytes_team(h->dn), h->stream, h->dn_dev, h->dp_dev, Wc, A);

@@ -15,7 +15,7 @@ module racgpu
   public :: racgpu_network_load, racgpu_network_destroy, racgpu_network_dims, racgpu_species_name, &
             racgpu_species_index, racgpu_load_initial_abundances, racgpu_params_default, racgpu_n_record, &
             racgpu_set_tolerances, racgpu_init_abundances, racgpu_set_device, racgpu_device_count, &
-            racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_column_sweep, racgpu_rectify_abundances, &
+            racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_column_sweep, racgpu_set_co_shielding_table, racgpu_rectify_abundances, &
             racgpu_set_cost_hints, racgpu_set_team_threshold, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
   public :: racgpu_error_string, chemsol_to_c, c_string
 
@@ -191,6 +191,14 @@ module racgpu
       type(c_ptr), value :: h
       real(c_double), dimension(*), intent(in) :: cost
       integer(c_int64_t), value :: ncell
+      integer(c_int) :: rc
+    end function
+    ! 12CO shielding table for racgpu_column_sweep: f(ncol, nrow) over ascending logN_12CO(ncol), logN_H2(nrow)
+    function racgpu_set_co_shielding_table(h, nrow, ncol, logN_H2, logN_12CO, f) bind(c, name='racgpu_set_co_shielding_table') result(rc)
+      import :: c_ptr, c_int32_t, c_double, c_int
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: nrow, ncol
+      real(c_double), dimension(*), intent(in) :: logN_H2, logN_12CO, f
       integer(c_int) :: rc
     end function
     ! the sweep in dependency order for grids whose cells form columns (include/racgpu.h): columns top down, the toISM self-shielding

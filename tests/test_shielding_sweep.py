@@ -151,9 +151,10 @@ def test_column_sweep_on_the_device_is_the_layer_sweep(racgpu):
     dz = np.linspace(0.5e13, 2e13, ncell)
     p = racgpu.default_params(); p.t_max = 1e3
     grid[:, racgpu.cells.P_TMAX] = 0.0
-    iH2, iH2O, iOH = (net.species_index(nm) - 1 for nm in ("H2", "H2O", "OH"))
+    iH2, iH2O, iOH, iCO = (net.species_index(nm) - 1 for nm in ("H2", "H2O", "OH", "CO"))
     C = racgpu.cells
     dv = 1.3e5
+    table = (G["co_logN_H2"], G["co_logN_12CO"], G["co_f_nodes"])  # (the reference's function sampled on a node grid of ours)
 
     def update(k, idx, cells_, y_done, done):
         n = np.zeros(ncell)
@@ -163,15 +164,24 @@ def test_column_sweep_on_the_device_is_the_layer_sweep(racgpu):
             n[:] = 0.0
             n[done] = cells_[done, C.P_NGAS] * y_done[done, sp]
             cells_[idx, slot] = f(C.column_density_above(n, dz, column, layer)[idx])
+        nh2 = np.zeros(ncell); nco = np.zeros(ncell)
+        nh2[done] = cells_[done, C.P_NGAS] * y_done[done, iH2]; nco[done] = cells_[done, C.P_NGAS] * y_done[done, iCO]
+        cells_[idx, C.P_FSS_ISM_CO] = C.co_shielding(table, C.column_density_above(nh2, dz, column, layer)[idx],
+                                                     C.column_density_above(nco, dz, column, layer)[idx])
 
     cells_h = grid.copy()
     host = racgpu.sweep.solve_by_layers(lambda cb, yb: net.evol_solve_batch(p, cb, yb), cells_h, net.init_abundances(y0, grid), layer, update)
     col_cells = np.concatenate([np.nonzero(column == c)[0][np.argsort(layer[column == c])] for c in range(ncol)])
     col_ptr = np.arange(ncol + 1) * nz
+    net.set_co_shielding_table(table)
     dev = net.column_sweep(p, grid, net.init_abundances(y0, grid), col_ptr, col_cells, dz, dv_turb=dv)
-    for slot in (C.P_FSS_ISM_H2, C.P_FSS_ISM_H2O, C.P_FSS_ISM_OH):
-        np.testing.assert_allclose(dev["cells"][:, slot], cells_h[:, slot], rtol=1e-6)  # (their inputs are end states: see below)
-    untouched = [k for k in range(racgpu.NPAR) if k not in (C.P_FSS_ISM_H2, C.P_FSS_ISM_H2O, C.P_FSS_ISM_OH)]
+    net.set_co_shielding_table(None)
+    nocotable = net.column_sweep(p, grid, net.init_abundances(y0, grid), col_ptr, col_cells, dz, dv_turb=dv)
+    np.testing.assert_array_equal(nocotable["cells"][:, C.P_FSS_ISM_CO], grid[:, C.P_FSS_ISM_CO])  # without a table the slot stays
+    for slot in (C.P_FSS_ISM_H2, C.P_FSS_ISM_H2O, C.P_FSS_ISM_OH, C.P_FSS_ISM_CO):
+        # (their inputs are end states, equal to the noise floor below; the CO factor is the steepest function of them)
+        np.testing.assert_allclose(dev["cells"][:, slot], cells_h[:, slot], rtol=1e-4 if slot == C.P_FSS_ISM_CO else 1e-6)
+    untouched = [k for k in range(racgpu.NPAR) if k not in (C.P_FSS_ISM_H2, C.P_FSS_ISM_H2O, C.P_FSS_ISM_OH, C.P_FSS_ISM_CO)]
     np.testing.assert_array_equal(dev["cells"][:, untouched], grid[:, untouched])
     top = layer == 0
     np.testing.assert_array_equal(dev["y"][top], host["y"][top])
