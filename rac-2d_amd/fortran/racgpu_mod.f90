@@ -205,9 +205,9 @@ module racgpu
     ! slots of H2, H2O and OH rewritten on the device from the cells above; col_ptr/col_cells are 0-based
     function racgpu_column_sweep(h, p, ncolumn, col_ptr, col_cells, ncell, cells, y, dz, dv_turb, t_final, quality, stats, &
                                  cell_out, mem) bind(c, name='racgpu_column_sweep') result(rc)
-      import :: c_ptr, c_int64_t, c_int32_t, c_double, c_int, racgpu_params
+      import :: c_ptr, c_int64_t, c_int32_t, c_double, c_int, racgpu_params_t
       type(c_ptr), value :: h
-      type(racgpu_params), intent(in) :: p
+      type(racgpu_params_t), intent(in) :: p
       integer(c_int64_t), value :: ncolumn, ncell
       integer(c_int32_t), dimension(*), intent(in) :: col_ptr, col_cells
       real(c_double), dimension(*), intent(inout) :: cells, y
