@@ -48,3 +48,13 @@ def test_k_solve_has_no_scratch_and_fits_three_waves_per_simd():
         assert int(k["Occupancy"]) >= 3, (name, k)
     for name, v in kernels.items():                # no kernel of the library may use scratch
         assert int(v["ScratchSize"]) == 0, (name, v)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/amdflang"), reason="no amdflang")
+def test_fortran_binding_module_compiles(tmp_path):
+    """The ISO_C_BINDING module is part of the boundary: every interface block must compile (the GPU tests run a prebuilt host
+    binary, which a broken module would leave stale)."""
+    src = os.path.join(ROOT, "rac-2d_amd", "fortran", "racgpu_mod.f90")
+    out = subprocess.run(["/opt/rocm/bin/amdflang", "-O0", "-c", src, "-o", str(tmp_path / "racgpu_mod.o"), "-J", str(tmp_path)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
