@@ -163,14 +163,25 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
       bool lost = false;
       const rsrc_t bP = mkbuf(c.Pv), bD = mkbuf(N.Pdiag);
       const int l8 = c.lane * 8;
-      for (int e0 = 0; e0 < N.nnzJ; e0 += 64) { // (the wave's slice of P ends at nnzJ: the next slot's slice follows directly)
-        double pij = bload_f64(bP, l8, e0 * 8);
-        const bool in = e0 + c.lane < N.nnzJ;
-        const bool dg = in && bload_u8(bD, c.lane, e0) != 0; // P is stored in permuted-column order
-        if (dg) { pij = pij - 1.0; if (fabs(pij) < kPsmall) lost = true; }
-        pij = pij * rcon;
-        if (dg) pij = pij + 1.0;
-        if (in) bstore_f64(bP, l8, e0 * 8, pij);
+      constexpr int B = 8; // blocks per trip, every load of a trip before any use: a trip costs one memory round trip, not B
+      for (int c0 = 0; c0 < N.nnzJ; c0 += 64 * B) { // (the wave's slice of P ends at nnzJ: the next slot's slice follows directly)
+        double pv[B]; uint8_t dv[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+          const int e0 = min(c0 + 64 * u, (N.nnzJ - 1) / 64 * 64); // (blocks past the end re-read the last one; P and Pdiag are padded by 64)
+          pv[u] = bload_f64(bP, l8, e0 * 8); dv[u] = bload_u8(bD, c.lane, e0);
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+          const int e0 = c0 + 64 * u;
+          double pij = pv[u];
+          const bool in = e0 + c.lane < N.nnzJ;
+          const bool dg = in && dv[u] != 0; // P is stored in permuted-column order
+          if (dg) { pij = pij - 1.0; if (fabs(pij) < kPsmall) lost = true; }
+          pij = pij * rcon;
+          if (dg) pij = pij + 1.0;
+          if (in) bstore_f64(bP, l8, e0 * 8, pij);
+        }
       }
       if (wave_any(lost)) { s.iplost = 1; s.conmin = fmin(fabs(s.con0), s.conmin); }
     }
