@@ -842,9 +842,21 @@ RG_DEV void dev_solve(const DevNet &N, const double *__restrict__ Lv, const doub
     }
 #undef RG_DS_LOAD
   }
-  for (int i = lane; i < ns; i += 64) w[i] = w[i] * Dinv[i];
-  if (hasA) xA = xA * Dinv[rowA];
-  if (hasB) xB = xB * Dinv[rowB];
+  // D^-1: four blocks' loads go out before any is used (they were one memory round trip each)
+  {
+    const rsrc_t bD = mkbuf(Dinv);
+    const int l8d = lane * 8;
+    const double dA = bload_f64(bD, min(rowA, N.npad - 1) * 8, 0), dB = bload_f64(bD, min(rowB, N.npad - 1) * 8, 0);
+    for (int c0 = 0; c0 < ns; c0 += 256) {
+      double dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dv[u] = bload_f64(bD, l8d, min(c0 + 64 * u, N.npad - 64) * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = c0 + 64 * u + lane; if (i < ns) w[i] = w[i] * dv[u]; }
+    }
+    if (hasA) xA = xA * dA;
+    if (hasB) xB = xB * dB;
+  }
   if (nt > 1) {
     // backward: columns k = n-1 .. ns+1 of U, rows ns .. k-1; byte offset of U(0, k): ((nzus + kk (kk-1)/2) - ns) * 8.
     // Columns kk >= 64: all of A, B above the diagonal; in whole groups of D while they last, the rest one by one.
