@@ -84,7 +84,9 @@ enum { RACGPU_S_NST = 0, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_NERR
                           (src/disk.f90:1716-1721); <= 1 means "No useful data produced": y and t_final were left alone */
        RACGPU_S_NITER, /* local iterations used (racgpu_calc_cells; 1 for a plain solve) */
        RACGPU_S_NREC,  /* n_record of this cell's (last) run, from its own t0, t_max and first step (src/chemistry.f90:1916-1938) */
-       RACGPU_S_SPARE };
+       RACGPU_S_ERRCODES /* the error returns behind NERR by ISTATE code, 16 bits each from bit 0: -1 (MXSTEP), -4 (error test), -5
+                            (convergence), any other; like NERR, of the last local iteration that proceeded (ode_solver_error_handling,
+                            src/chemistry.f90:272-387) */ };
 
 /* per-cell values the path writes back into the cell record (double x RACGPU_NOUT per cell) */
 #define RACGPU_NOUT 3
@@ -203,7 +205,8 @@ int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
  * get_H2_self_shielding(N_H2, dv_turb) (:1887-1897), H2O and OH by exp(-N sigma_Lya) (:1847-1859), CO by get_12CO_shielding(N_H2,
  * N_CO) on the table given to racgpu_set_co_shielding_table (without one the CO slot stays as given), all capped at 1; the toStar
  * slots stay as given (they need ray tracing).  cells is updated in place; everything
- * else as racgpu_evol_solve_batch with t0 = 0 and the handle's default tolerance policy. */
+ * else as racgpu_evol_solve_batch with t0 = 0 and the handle's default tolerance policy.  The surface cell of a column gets the
+ * slots for N = 0.  col_cells must be a permutation of 0..ncell-1 (checked for host buffers). */
 /* 12CO shielding table for racgpu_column_sweep: f[ncol][nrow] > 0 over ascending log10 column densities logN_12CO[ncol], logN_H2[nrow]
  * (the layout of the reference's f_12CO(ncol, nrow), src/load_Visser_CO_selfshielding.f90; its own Visser et al. 2009 table is
  * compiled into it and not shipped here: the caller supplies one).  f == NULL clears it. */

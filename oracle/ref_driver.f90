@@ -121,6 +121,7 @@ program ref_driver
   open(newunit=fU, file=trim(cell_file), status='old', action='read')
   do ic = 1, ncell
     read(fU, *) cpar
+    write(chemsol_params%fU_log, '(A, I8)') '# cell ', ic  ! the error handler's "!Error: ISTATE" lines that follow belong to this cell
     chem_params%Tgas                      = cpar(1)
     chem_params%Tdust                     = cpar(2)
     chem_params%n_gas                     = cpar(3)

@@ -27,7 +27,7 @@ NOUT = 3
 MEM_HOST, MEM_DEVICE = 0, 1
 F_RECTIFY = 1
 (S_NST, S_NFE, S_NJE, S_NLU, S_NERR, S_NREC_REAL, S_QSUM, S_NCFAIL_ETFAIL, S_CYC_TOTAL, S_CYC_RHS, S_CYC_JAC, S_CYC_LU,
- S_CYC_SOLVE, S_CYC_LU_SCATTER, S_CYC_LU_LDS, S_CYC_LU_REG, S_ISAV, S_NITER, S_NREC, S_SPARE) = range(NSTAT)
+ S_CYC_SOLVE, S_CYC_LU_SCATTER, S_CYC_LU_LDS, S_CYC_LU_REG, S_ISAV, S_NITER, S_NREC, S_ERRCODES) = range(NSTAT)
 O_R_H2_FORM, O_N_MOL_ON_GRAIN, O_T_END = range(NOUT)
 
 # every extern "C" symbol include/racgpu.h declares (tests check that the library exports all of them)

@@ -174,7 +174,7 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
   g_wc.inv_neq = 1.0 / (double)(n + 1);
   if (TEAM > 1 && !RESUME && lane == 0) atomicAdd(W.counter - 1, 1); // k_gate: this workgroup is resident (the team queue's counter is word [2], this is [1])
   const int nparked = RESUME ? gptr(A.park_count)[0] : 0;
-  int kpos = 0, kend = 0, kfirst = 0; // COLUMN: the wave's place in its column's cell list
+  int kpos = 0, kend = 0; // COLUMN: the wave's place in its column's cell list
   for (;;) {
     int cell = 0;
     if (!COLUMN || kpos >= kend) { // the next work item: a cell, a parked cell or a column
@@ -187,11 +187,11 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
     if (COLUMN) {
       if (kpos >= kend) {
         if (cell >= A.ncolumn) break;
-        kpos = kfirst = A.col_ptr[cell]; kend = A.col_ptr[cell + 1]; // (never empty: racgpu_column_sweep checks)
+        kpos = A.col_ptr[cell]; kend = A.col_ptr[cell + 1]; // (never empty: racgpu_column_sweep checks)
         g_col.N_H2 = 0.0; g_col.N_H2O = 0.0; g_col.N_OH = 0.0; g_col.N_CO = 0.0;
       }
       cell = A.col_cells[kpos];
-      if (kpos > kfirst && lane == 0) {
+      if (lane == 0) { // (the surface cell too: column densities 0, as update_params_above_alt gives it, src/disk.f90:1840-1866)
         // update_params_above_alt's grid-free part (reference src/disk.f90:1840-1859) towards the surface: H2 by Draine &
         // Bertoldi 1996 eq. 37 (get_H2_self_shielding, :1887-1897; the 0.035 is a single-precision literal there), H2O and OH
         // by their Lyman-alpha cross sections (src/sub_global_variables.f90:82-83)
@@ -304,7 +304,7 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
         s[RACGPU_S_CYC_TOTAL] = dev_clock() - cyc0; s[RACGPU_S_CYC_RHS] = g_wc.cyc[CYC_RHS]; s[RACGPU_S_CYC_JAC] = g_wc.cyc[CYC_JAC];
         s[RACGPU_S_CYC_LU] = g_wc.cyc[CYC_LU]; s[RACGPU_S_CYC_SOLVE] = g_wc.cyc[CYC_SOLVE];
         s[13] = g_wc.cyc[CYC_LU_PART]; s[14] = g_wc.cyc[CYC_LU_PART + 1]; s[15] = g_wc.cyc[CYC_LU_PART + 2]; // finish = LU - the three
-        s[RACGPU_S_ISAV] = R.isav; s[RACGPU_S_NITER] = 1; s[RACGPU_S_NREC] = nrec; s[19] = 0;
+        s[RACGPU_S_ISAV] = R.isav; s[RACGPU_S_NITER] = 1; s[RACGPU_S_NREC] = nrec; s[RACGPU_S_ERRCODES] = R.errc;
       }
     }
     if (COLUMN) { // what this cell adds to the columns above the next one: its hand-off abundances (as the caller now has them)
@@ -386,7 +386,7 @@ __global__ void k_merge_pass(int nsel, const int *__restrict__ sel, int nS, int 
     if (proceeds) { // (an iteration that does not proceed leaves NITER behind: the host loop stops the cell on that)
       s[RACGPU_S_NITER] = j;
       s[RACGPU_S_NERR] = sc[RACGPU_S_NERR]; s[RACGPU_S_NREC_REAL] = sc[RACGPU_S_NREC_REAL]; s[RACGPU_S_ISAV] = sc[RACGPU_S_ISAV];
-      s[RACGPU_S_NREC] = sc[RACGPU_S_NREC];
+      s[RACGPU_S_NREC] = sc[RACGPU_S_NREC]; s[RACGPU_S_ERRCODES] = sc[RACGPU_S_ERRCODES];
       if (cell_out) cell_out[(size_t)cell * RACGPU_NOUT + RACGPU_O_T_END] = out_c[(size_t)f * RACGPU_NOUT + RACGPU_O_T_END];
       quality[cell] = quality_c[f];
       if (useful) {
@@ -1353,7 +1353,12 @@ int racgpu_column_sweep(racgpu_network *h, const racgpu_params *p, int64_t ncolu
     if (mem == RACGPU_MEM_HOST) { // (device buffers are the caller's responsibility)
       if (col_ptr[0] != 0 || col_ptr[ncolumn] != ncell) throw std::runtime_error("column sweep: col_ptr must run from 0 to ncell");
       for (int64_t c = 0; c < ncolumn; ++c) if (col_ptr[c + 1] <= col_ptr[c]) throw std::runtime_error("column sweep: empty column");
-      for (int64_t i = 0; i < ncell; ++i) if (col_cells[i] < 0 || col_cells[i] >= ncell) throw std::runtime_error("column sweep: cell index out of range");
+      std::vector<char> seen((size_t)ncell, 0); // two columns holding the same cell would integrate it at once and corrupt each other's output
+      for (int64_t i = 0; i < ncell; ++i) {
+        if (col_cells[i] < 0 || col_cells[i] >= ncell) throw std::runtime_error("column sweep: cell index out of range");
+        if (seen[col_cells[i]]) throw std::runtime_error("column sweep: col_cells must be a permutation of the cells (duplicate index)");
+        seen[col_cells[i]] = 1;
+      }
     }
     h->ws.trace = nullptr; h->ws.marker = nullptr;
     const long grid = std::min<long>(ncolumn, 2L * h->cu_count); // two teams per CU by registers

@@ -581,7 +581,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
       }
     }
     lds_sync();
-    if (nteam > 1) team_barrier(); // every wave's D^-1 of these columns is in the shared LDS copy
+    if (nteam > 1) { if (!ok) *tfail = 1; team_barrier(); } // every wave's D^-1 of these columns is in the shared LDS copy
     for (int q0 = 64 * wv; q0 < N.nleaf_ent; q0 += 64 * nteam) {
       const unsigned long long e = bload_u64(bLe, l8, q0 * 8);
       if (q0 + lane < N.nleaf_ent)
@@ -602,6 +602,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     prime(0);
     for (int l = 0; l < N.team_nlev; ++l) {
       for (int c = lp[l]; c < lp[l + 1]; ++c) { rect_phase(c, w); RG_TICK(c_dense) finish(cur.j, w); }
+      if (!ok) *tfail = 1; // (a network without trailing columns never reaches the rounds below, where the flag is otherwise raised)
       team_barrier(); // this level's columns and their D^-1 are in place for the whole team
     }
     cols = gptr(reinterpret_cast<const int *>(N.lucol));

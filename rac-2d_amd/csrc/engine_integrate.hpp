@@ -456,6 +456,7 @@ struct EvolState {
   double t, t_step, tout, t_good, rt_total, rt_last;
   long long nst_acc, nfe_acc, nje_acc, nlu_acc;
   int istate, nerr, nerr_c, qual, nrr, isav;
+  long long errc; // error returns by ISTATE code, 16 bits each: -1, -4, -5, any other
 };
 
 // A cell between two integrator steps, set aside by the wave that was solving it (k_solve once the queue is empty and few waves
@@ -631,7 +632,7 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
 // chem_evol_solve for one cell.  y (LDS) in: abundances at t0; out: abundances at the end of the run.
 // ygood (HBM): the hand-off record, i.e. record(:, isav) of the caller's loop in calc_this_cell (reference
 // src/disk.f90:1716-1733): the last record whose T and H2 entries are not NaN.
-struct CellResult { double t_final, t_good; int quality, nerr, nrec_real, isav; long long nst, nfe, nje, nlu, qsum; int nfail; bool parked; };
+struct CellResult { double t_final, t_good; int quality, nerr, nrec_real, isav; long long nst, nfe, nje, nlu, qsum, errc; int nfail; bool parked; };
 
 
 RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const CellCtx &c, double t0, double t_max, double dt_first,
@@ -645,7 +646,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     s = Lsodes{};
     s.trace = trace; s.trace_cap = P.debug_max_calls;
     s.tcrit = t_max; s.hmxi = (t_max > 0.0) ? 1.0 / t_max : 0.0; s.mxstep = P.mxstep > 0 ? P.mxstep : 500;
-    e.istate = 1; e.nerr = 0; e.nerr_c = 0; e.qual = 0; e.nrr = 1; e.isav = 1;
+    e.istate = 1; e.nerr = 0; e.nerr_c = 0; e.qual = 0; e.nrr = 1; e.isav = 1; e.errc = 0;
     e.t = t0; e.t_step = dt_first; e.tout = t0 + dt_first; e.t_good = t0;
     e.nst_acc = 0; e.nfe_acc = 0; e.nje_acc = 0; e.nlu_acc = 0;
     // Deterministic stand-in for the reference's CPU-time guards (src/chemistry.f90:438, 480-491): the time the
@@ -661,7 +662,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     const EvolState &pe = io.rec->e;
     e.t = pe.t; e.t_step = pe.t_step; e.tout = pe.tout; e.t_good = pe.t_good; e.rt_total = pe.rt_total; e.rt_last = pe.rt_last;
     e.nst_acc = pe.nst_acc; e.nfe_acc = pe.nfe_acc; e.nje_acc = pe.nje_acc; e.nlu_acc = pe.nlu_acc;
-    e.istate = pe.istate; e.nerr = pe.nerr; e.nerr_c = pe.nerr_c; e.qual = pe.qual; e.nrr = pe.nrr; e.isav = pe.isav;
+    e.istate = pe.istate; e.nerr = pe.nerr; e.nerr_c = pe.nerr_c; e.qual = pe.qual; e.nrr = pe.nrr; e.isav = pe.isav; e.errc = pe.errc;
   }
   bool parked = false;
   int park0[4] = {0, 0, 0, 0};
@@ -705,6 +706,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     if (t >= s.tcrit) break;
     if (istate < 0) {
       e.nerr = e.nerr + 1; e.nerr_c = e.nerr_c + 1;
+      e.errc = e.errc + (1ll << (istate == -1 ? 0 : istate == -4 ? 16 : istate == -5 ? 32 : 48));
       if (istate == -4 || istate == -5) { // loosen the offending component's tolerances
         const int idx = s.imxer;
         if (lane == 0) { c.rtol[idx] = fmin(c.rtol[idx] * 10.0, 1e-3); c.atol[idx] = fmin(c.atol[idx] * 100.0, 1e-20); }
@@ -737,7 +739,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
       EvolState &pe = r->e;
       pe.t = e.t; pe.t_step = e.t_step; pe.tout = e.tout; pe.t_good = e.t_good; pe.rt_total = e.rt_total; pe.rt_last = e.rt_last;
       pe.nst_acc = e.nst_acc; pe.nfe_acc = e.nfe_acc; pe.nje_acc = e.nje_acc; pe.nlu_acc = e.nlu_acc;
-      pe.istate = e.istate; pe.nerr = e.nerr; pe.nerr_c = e.nerr_c; pe.qual = e.qual; pe.nrr = e.nrr; pe.isav = e.isav;
+      pe.istate = e.istate; pe.nerr = e.nerr; pe.nerr_c = e.nerr_c; pe.qual = e.qual; pe.nrr = e.nrr; pe.isav = e.isav; pe.errc = e.errc;
       WaveConst &wc = r->wc;
       wc.nsite = g_wc.nsite; wc.Tgas = g_wc.Tgas; wc.rT = g_wc.rT; wc.aT = g_wc.aT; wc.inv_neq = g_wc.inv_neq;
       for (int k = 0; k < 8; ++k) wc.cyc[k] = g_wc.cyc[k];
@@ -765,7 +767,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
   if (t <= 0.5 * s.tcrit) qual += 2;
   CellResult R{};
   R.t_final = t; R.t_good = e.t_good; R.isav = e.isav; R.quality = qual; R.nerr = e.nerr; R.nrec_real = nrr;
-  R.nst = e.nst_acc; R.nfe = e.nfe_acc; R.nje = e.nje_acc; R.nlu = e.nlu_acc; R.qsum = s.qsum; R.nfail = s.nfail;
+  R.nst = e.nst_acc; R.nfe = e.nfe_acc; R.nje = e.nje_acc; R.nlu = e.nlu_acc; R.qsum = s.qsum; R.nfail = s.nfail; R.errc = e.errc;
   return R;
 }
 

@@ -514,9 +514,13 @@ void build_reference_layout(HostNetwork &net) {
   // IWORK(17) (LENRW) as the reference's DLSODES reports it for the networks shipped in data/ (measured with
   // oracle/_ref/ref_driver, section '# workspace'); it depends on YSMP's compressed index storage and cannot be derived
   // without it.  Other networks: racgpu_network_set_reference_lenrw, or 0 = the saved P is taken to survive ISTATE = 3.
-  static const struct { int nS, nR, lenrw; } known[] = {{464, 4767, 59430}, {467, 4801, 60324}, {484, 5830, 65578}, {524, 6425, 82134}};
+  // Keyed on the pattern's own sizes as well (entries before / after DPREP's diagonal additions): a user network with the same
+  // species and reaction counts but another sparsity pattern must not inherit another network's LENRW.
+  static const struct { int nS, nR, nnz0, nnz1, lenrw; } known[] = {{464, 4767, 13348, 13351, 59430}, {467, 4801, 13469, 13472, 60324},
+                                                                    {484, 5830, 14994, 14994, 65578}, {524, 6425, 18205, 18205, 82134}};
   net.ref_lenrw = 0;
-  for (const auto &k : known) if (k.nS == nS && k.nR == net.nR) net.ref_lenrw = k.lenrw;
+  for (const auto &k : known)
+    if (k.nS == nS && k.nR == net.nR && k.nnz0 == net.ref_nnz0 && k.nnz1 == net.ref_nnz1) net.ref_lenrw = k.lenrw;
 }
 
 } // namespace racgpu

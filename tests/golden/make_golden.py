@@ -222,6 +222,76 @@ def main_policy():
         print(k, "\n", out[k])
 
 
+def error_codes(log, ncell):
+    """Per cell, how often the reference's error handler saw ISTATE = -1, -4, -5, anything else: [ncell, 4] (ref_driver writes a
+    '# cell k' line into the log before each cell; ode_solver_error_handling writes '!Error: <ISTATE>' per error return)."""
+    out = np.zeros((ncell, 4), dtype=np.int64)
+    cur = -1
+    for line in log.splitlines():
+        if line.startswith("# cell"):
+            cur = int(line.split()[2]) - 1
+        elif line.startswith("!Error:") and cur >= 0:
+            p = line.split()
+            if len(p) == 2 and p[1].lstrip("-").isdigit():
+                out[cur, {-1: 0, -4: 1, -5: 2}.get(int(p[1]), 3)] += 1
+    return out
+
+
+def run_ref_parallel(network, initial, cells, rtol, t_max, nproc=8, **kw):
+    """run_ref over interleaved slices of `cells`, one process each; returns the per-cell dicts in order."""
+    from concurrent.futures import ThreadPoolExecutor
+    parts = [np.arange(w, len(cells), nproc) for w in range(nproc)]
+    parts = [p for p in parts if len(p)]
+    with ThreadPoolExecutor(len(parts)) as ex:
+        res = list(ex.map(lambda p: run_ref(network, initial, cells[p], rtol, t_max, 50, 0, **kw)[0], parts))
+    out = [None] * len(cells)
+    codes = np.zeros((len(cells), 4), dtype=np.int64)
+    for p, r in zip(parts, res):
+        ec = error_codes(r[0]["_log"], len(p))
+        for k, i in enumerate(p):
+            out[i] = r[k]; codes[i] = ec[k]
+    return out, codes
+
+
+def main_grid64():
+    """tests/golden/grid64_grain.npz: 64 cells of the configs[2] grid -- every fourth cell of bench.py's 256-cell parity sample --
+    with the reference's end state at the template settings ("cfg"), with n_gas moved by one ulp ("ulp": that cell's own noise
+    floor), at RTOL 1e-8 ("tight") and at RTOL 1e-10 ("tighter": how far the reference's own RTOL 1e-8 answer is from converged),
+    plus NERR and the ISTATE codes behind it."""
+    andrews_grid = importlib.import_module("rac-2d_amd.cells").andrews_grid
+    grid = andrews_grid()
+    network, initial = "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "ini_abund_waterice_loMetal.dat"
+    ncell = len(grid)
+    sample = np.arange(256) * (ncell // 256) + (ncell // 256) // 2  # bench.py's sample_idx for 16 host cores
+    idx = sample[::4]
+    cells = grid[idx]
+    cells_ulp = cells.copy()
+    cells_ulp[:, 2] = np.nextafter(cells_ulp[:, 2], np.inf)
+    cells_ulp[:, 5] = cells_ulp[:, 2] * cells_ulp[:, 6]
+    cfg, ec_cfg = run_ref_parallel(network, initial, cells, 1e-4, 1e6)
+    ulp, ec_ulp = run_ref_parallel(network, initial, cells_ulp, 1e-4, 1e6)
+    tight, ec_t = run_ref_parallel(network, initial, cells, 1e-8, 1e6)
+    tighter, ec_tt = run_ref_parallel(network, initial, cells, 1e-10, 1e6)
+    out = dict(network_file=network, initial_file=initial, grid_idx=idx, cells=cells, cells_ulp=cells_ulp,
+               yend=np.array([c["yend"] for c in cfg]), scalars=np.array([c["scalars"][:3] for c in cfg]), errcodes=ec_cfg,
+               stats=np.array([c["stats"] for c in cfg]),
+               yend_ulp=np.array([c["yend"] for c in ulp]), scalars_ulp=np.array([c["scalars"][:3] for c in ulp]), errcodes_ulp=ec_ulp,
+               yend_tight=np.array([c["yend"] for c in tight]), scalars_tight=np.array([c["scalars"][:3] for c in tight]), errcodes_tight=ec_t,
+               yend_tighter=np.array([c["yend"] for c in tighter]), scalars_tighter=np.array([c["scalars"][:3] for c in tighter]))
+    fn = os.path.join(HERE, "grid64_grain.npz")
+    np.savez_compressed(fn, **out)
+    nS = out["yend"].shape[1] - 1
+    ye, yu, yt, ytt = (out[k][:, :nS] for k in ("yend", "yend_ulp", "yend_tight", "yend_tighter"))
+    fl, tt = [], []
+    for i in range(len(idx)):
+        m = ye[i] >= 1e-6
+        fl.append(np.max(np.abs(ye[i][m] - yu[i][m]) / ye[i][m]))
+        m = ytt[i] >= 1e-6
+        tt.append(np.max(np.abs(yt[i][m] - ytt[i][m]) / ytt[i][m]))
+    print("wrote", fn, os.path.getsize(fn) // 1024, "KiB; 1-ulp floor: median %.1e max %.1e; 1e-8 vs 1e-10: median %.1e max %.1e; NERR cfg %d ulp %d tight %d"
+          % (np.median(fl), np.max(fl), np.median(tt), np.max(tt), out["scalars"][:, 2].sum(), out["scalars_ulp"][:, 2].sum(), out["scalars_tight"][:, 2].sum()))
+
+
 def main_shielding():
     """tests/golden/shielding.npz: the reference's self-shielding functions (oracle/_ref/ref_shielding) at seeded points.
     H2: 256 points.  CO: the function sampled on a coarse node grid of OURS (the table the product helper is then given) and at
@@ -249,6 +319,8 @@ if __name__ == "__main__":
         main_shielding()
     elif len(sys.argv) > 1 and sys.argv[1] == "policy":
         main_policy()
+    elif len(sys.argv) > 1 and sys.argv[1] == "grid64":
+        main_grid64()
     else:
         main()
         main_policy()

@@ -1,8 +1,8 @@
 """Developer aid: conservation statistics of a synthetic batch (see tests/test_gpu_fullsize.py)."""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
 import oracle_ctypes as O
 R = importlib.import_module("rac-2d_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048

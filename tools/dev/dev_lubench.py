@@ -3,9 +3,9 @@ RACGPU_DEBUG_REPEAT=R makes racgpu_newton_solve repeat both R times per cell and
 import importlib, sys, os
 import numpy as np
 os.environ.setdefault("RACGPU_DEBUG_REPEAT", "20")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 R = importlib.import_module("rac-2d_amd")
-d = np.load("tests/dev_state9565.npz")
+d = np.load("tools/dev/dev_state9565.npz")
 net = R.Network("data/rate06_dipole_reformated_again_withoutgrain.dat")
 p = R.default_params(); nS = net.nSpecies
 for ncell in [int(a) for a in sys.argv[1:]] or [256, 2048]:

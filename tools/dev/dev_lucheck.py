@@ -1,9 +1,9 @@
 """Developer aid: accuracy of the device LDU solve at a recorded state, against a dense pivoted solve."""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 R = importlib.import_module("rac-2d_amd")
-d = np.load("tests/dev_state9565.npz")
+d = np.load("tools/dev/dev_state9565.npz")
 net = R.Network("data/rate06_dipole_reformated_again_withoutgrain.dat")
 p = R.default_params(); nS = net.nSpecies
 y = d["y"][None, :]; cell = d["cell"][None, :]

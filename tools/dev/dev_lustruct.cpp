@@ -68,4 +68,4 @@ int main(int argc, char **argv) {
   }
   return 0;
 }
-// hipcc -O2 -std=c++17 tests/dev_lustruct.cpp rac-2d_amd/csrc/network.o -o build/dev_lustruct
+// hipcc -O2 -std=c++17 tools/dev/dev_lustruct.cpp rac-2d_amd/csrc/network.o -o build/dev_lustruct

@@ -1,8 +1,8 @@
 """Developer probe (not a test): one cell, increasing horizons, GPU vs oracle, with wall times."""
 import importlib, sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
 R = importlib.import_module("rac-2d_amd")
 import oracle_ctypes as O
 D = "data/"

@@ -1,8 +1,8 @@
 """Developer aid: GPU record of one synthetic cell vs the oracle's, species-wise, around a given time."""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle"))
 R = importlib.import_module("rac-2d_amd")
 import oracle_ctypes as O
 idx = int(sys.argv[1]); tprobe = float(sys.argv[2])

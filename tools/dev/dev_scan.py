@@ -1,7 +1,7 @@
 """Developer scan (not a test): per-cell statistics of a synthetic batch, saved for analysis."""
 import importlib, sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 R = importlib.import_module("rac-2d_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 maxsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 0

@@ -1,7 +1,7 @@
 """Developer scan (not a test): per-cell statistics of the synthetic Andrews grid (BASELINE configs[2]), saved for analysis."""
 import importlib, sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 R = importlib.import_module("rac-2d_amd")
 netfile = sys.argv[1] if len(sys.argv) > 1 else "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat"
 stride = int(sys.argv[2]) if len(sys.argv) > 2 else 1

@@ -1,7 +1,7 @@
 """Developer aid: ulp-variants of given synthetic cells on the GPU (is a slow cell intrinsically slow, or a rare event?)."""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 R = importlib.import_module("rac-2d_amd")
 net = R.Network("data/rate06_dipole_reformated_again_withoutgrain.dat")
 y0 = net.load_initial_abundances("data/ini_abund_waterice_loMetal.dat")
