@@ -78,9 +78,38 @@ def _read_sections(fn):
     return {k: np.array(v) for k, v in d.items()}
 
 
+def _error_codes(logfile, ncell):
+    """[ncell, 4]: how often the reference's error handler (ode_solver_error_handling) saw ISTATE -1, -4, -5, anything else, per cell
+    (ref_driver writes '# cell k' into its log before each cell, the handler '!Error: <ISTATE>' per error return)."""
+    out = np.zeros((ncell, 4), dtype=np.int64)
+    cur = -1
+    try:
+        for line in open(logfile, errors="replace"):
+            if line.startswith("# cell"):
+                cur = int(line.split()[2]) - 1
+            elif line.startswith("!Error:") and 0 <= cur < ncell:
+                p = line.split()
+                if len(p) == 2 and p[1].lstrip("-").isdigit():
+                    out[cur, {-1: 0, -4: 1, -5: 2}.get(int(p[1]), 3)] += 1
+    except OSError:
+        pass
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def run_reference(sample, network, initial, params, rtol=None):
     """oracle/_ref/ref_driver on the rows of `sample`, one process per host core; returns (list of section dicts, seconds, cores)
-    or (None, 0, cores) when the binary is absent or fails."""
+    or (None, 0, cores) when the binary is absent or fails.  Every dict also carries "errcodes": the cell's error returns by ISTATE
+    code (-1, -4, -5, other)."""
     cores = min(os.cpu_count() or 1, 16)
     driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if not os.path.exists(driver):
@@ -110,8 +139,10 @@ def run_reference(sample, network, initial, params, rtol=None):
             return None, dt, cores
         ref = {}
         for w, d, m in dirs:
+            ec = _error_codes(os.path.join(d, "ref_log.txt"), m)
             for k in range(m):
                 ref[w + k * cores] = _read_sections(os.path.join(d, "cell_%04d.txt" % (k + 1)))
+                ref[w + k * cores]["errcodes"] = ec[k]
     return [ref[k] for k in range(len(sample))], dt, cores
 
 
@@ -123,42 +154,80 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
     nsample = len(sample)
     ref, dt, cores = run_reference(sample, network, initial, params)
     if ref is not None:
-        if True:
-            steps = float(np.sum(gpu["nst"][sample_idx]))
-            base = {"value": steps / dt, "unit": "cell-steps/s", "cores": cores, "kind": "reference",
-                    "sample": "%d cells of the same batch (every %d-th), reference Fortran/DLSODES binary, %d processes, %.1f s wall; "
-                              "steps counted with the GPU run's NST for the same cells (DLSODES zeroes its own counter at every solver reset)"
-                              % (nsample, max(1, len(cells) // nsample), min(cores, nsample), dt)}
-            errs, tf_eq, q_eq, ne_eq, ne_ref, ne_gpu = [], 0, 0, 0, 0, 0
-            for k in range(nsample):
-                r = ref[k]
-                yr = r["yend"][:nS]
-                yg = gpu["y"][sample_idx[k]]
-                m = yr >= 1e-6
-                errs.append(float(np.max(np.abs(yg[m] - yr[m]) / yr[m])))
-                tf_eq += int(r["scalars"][0] == gpu["t_final"][sample_idx[k]])
-                q_eq += int(int(r["scalars"][1]) == int(gpu["quality"][sample_idx[k]]))
-                ne_eq += int(int(r["scalars"][2]) == int(gpu["nerr"][sample_idx[k]]))
-                ne_ref += int(r["scalars"][2]); ne_gpu += int(gpu["nerr"][sample_idx[k]])
-            errs = np.array(errs)
-            parity = {"against": "reference Fortran/DLSODES end states of the cpu_baseline sample, same RTOL (%g); species with X >= 1e-6" % params.RTOL,
-                      "cells": nsample, "max_rel_err": float(errs.max()), "median_rel_err": float(np.median(errs)),
-                      "p90_rel_err": float(np.percentile(errs, 90)), "cells_within_1e-4": int((errs <= 1e-4).sum()),
-                      "t_final_equal": tf_eq, "quality_equal": q_eq,
-                      "nerr_equal": ne_eq, "nerr_total_reference": ne_ref, "nerr_total_gpu": ne_gpu,  # error returns (ISTATE < 0) of the integrator
-                      "note": "at RTOL 1e-4 the reference moves by 1e-5...1e-3 against its own 1-ulp-perturbed twin (tests/golden yend_ulp); "
-                              "the RTOL 1e-8 pin (<= 2e-6) is tests/test_gpu_parity.py::test_tight_tolerance_run_matches_the_reference_truth"}
-            if tight is not None:  # the same comparison where trajectory noise does not limit it: RTOL 1e-8 on both sides
-                tidx, gy = tight
-                tref, tdt, _ = run_reference(cells[tidx], network, initial, params, rtol=1e-8)
-                if tref is not None:
-                    te = []
-                    for k in range(len(tidx)):
-                        yr = tref[k]["yend"][:nS]; m = yr >= 1e-6
-                        te.append(float(np.max(np.abs(gy[k][m] - yr[m]) / yr[m])))
-                    parity["tight"] = {"rtol": 1e-8, "cells": len(tidx), "max_rel_err": float(np.max(te)), "median_rel_err": float(np.median(te)),
-                                       "reference_seconds": tdt}
-            return base, parity
+        steps = float(np.sum(gpu["nst"][sample_idx]))
+        base = {"value": steps / dt, "unit": "cell-steps/s", "cores": cores, "kind": "reference", "cpu_model": cpu_model(),
+                "sample": "%d cells of the same batch (every %d-th), reference Fortran/DLSODES binary, %d processes, %.1f s wall; "
+                          "steps counted with the GPU run's NST for the same cells (DLSODES zeroes its own counter at every solver reset)"
+                          % (nsample, max(1, len(cells) // nsample), min(cores, nsample), dt)}
+        # The reference's own rounding-noise floor on THESE cells: the same binary on the same cells with n_gas moved by one ulp
+        # (the recipe of tests/golden/make_golden.py).  A cell's floor = how far that moves the reference's own end state.
+        twin_cells = sample.copy()
+        twin_cells[:, 2] = np.nextafter(twin_cells[:, 2], np.inf)
+        twin_cells[:, 5] = twin_cells[:, 2] * twin_cells[:, 6]
+        twin, _, _ = run_reference(twin_cells, network, initial, params)
+
+        def worst(yg, yr):
+            m = yr >= 1e-6
+            e = np.zeros_like(yr)
+            e[m] = np.abs(yg[m] - yr[m]) / yr[m]
+            return float(e.max()), int(e.argmax())
+
+        errs, floors, spec, tf_eq, q_eq, ne_eq = [], [], [], 0, 0, 0
+        codes_ref = np.zeros(4, dtype=np.int64); codes_twin = np.zeros(4, dtype=np.int64); codes_gpu = np.zeros(4, dtype=np.int64)
+        ne_ref_twin_eq = 0
+        for k in range(nsample):
+            r = ref[k]
+            yr = r["yend"][:nS]
+            e, sp = worst(gpu["y"][sample_idx[k]], yr)
+            errs.append(e); spec.append(sp)
+            floors.append(worst(twin[k]["yend"][:nS], yr)[0] if twin is not None else 0.0)
+            tf_eq += int(r["scalars"][0] == gpu["t_final"][sample_idx[k]])
+            q_eq += int(int(r["scalars"][1]) == int(gpu["quality"][sample_idx[k]]))
+            ne_eq += int(int(r["scalars"][2]) == int(gpu["nerr"][sample_idx[k]]))
+            codes_ref += r["errcodes"]
+            ec = int(gpu["errcodes"][sample_idx[k]])
+            codes_gpu += np.array([(ec >> s) & 0xffff for s in (0, 16, 32, 48)])
+            if twin is not None:
+                codes_twin += twin[k]["errcodes"]
+                ne_ref_twin_eq += int(int(r["scalars"][2]) == int(twin[k]["scalars"][2]))
+        errs = np.array(errs); floors = np.array(floors)
+        bound = np.maximum(1e-4, 3.0 * floors)
+        excess = errs / bound
+        kw = int(np.argmax(excess))
+        names = ("ISTATE -1", "ISTATE -4", "ISTATE -5", "other")
+        parity = {"against": "reference Fortran/DLSODES end states of the cpu_baseline sample, same RTOL (%g); species with X >= 1e-6" % params.RTOL,
+                  "cells": nsample, "max_rel_err": float(errs.max()), "median_rel_err": float(np.median(errs)),
+                  "p90_rel_err": float(np.percentile(errs, 90)), "cells_within_1e-4": int((errs <= 1e-4).sum()),
+                  # per-cell floor = the reference against its own twin with n_gas moved by ONE ulp, same cells, same settings
+                  "floor": {"median": float(np.median(floors)), "p90": float(np.percentile(floors, 90)), "max": float(floors.max()),
+                            "cells_reference_moves_more_than_1e-4": int((floors > 1e-4).sum())},
+                  "cells_within_max(1e-4,3*floor)": int((errs <= bound).sum()),
+                  "worst_cell": {"cell": int(sample_idx[kw]), "species_index": spec[kw], "err": float(errs[kw]), "floor": float(floors[kw]),
+                                 "err_over_bound": float(excess[kw])},
+                  "exceptions": [{"cell": int(sample_idx[k]), "species_index": spec[k], "err": float(errs[k]), "floor": float(floors[k])}
+                                 for k in np.nonzero(errs > bound)[0][:16]],
+                  "t_final_equal": tf_eq, "quality_equal": q_eq,
+                  # error returns (ISTATE < 0) of the integrator, by code, on the three sides: GPU, reference, reference's 1-ulp twin
+                  "nerr_equal": ne_eq, "nerr_equal_reference_vs_its_twin": ne_ref_twin_eq,
+                  "nerr_by_code": {"gpu": dict(zip(names, map(int, codes_gpu))), "reference": dict(zip(names, map(int, codes_ref))),
+                                   "reference_twin": dict(zip(names, map(int, codes_twin)))},
+                  "nerr_total_reference": int(codes_ref.sum()), "nerr_total_reference_twin": int(codes_twin.sum()), "nerr_total_gpu": int(codes_gpu.sum())}
+        if tight is not None:  # the same comparison where trajectory noise does not limit it: RTOL 1e-8 on both sides
+            tidx, gy = tight
+            tref, tdt, _ = run_reference(cells[tidx], network, initial, params, rtol=1e-8)
+            tref10, _, _ = run_reference(cells[tidx], network, initial, params, rtol=1e-10)  # how converged is the reference's own 1e-8 answer
+            if tref is not None:
+                te, ts, tf = [], [], []
+                for k in range(len(tidx)):
+                    e, sp = worst(gy[k], tref[k]["yend"][:nS])
+                    te.append(e); ts.append(sp)
+                    tf.append(worst(tref[k]["yend"][:nS], tref10[k]["yend"][:nS])[0] if tref10 is not None else 0.0)
+                kt = int(np.argmax(te))
+                parity["tight"] = {"rtol": 1e-8, "cells": len(tidx), "max_rel_err": float(np.max(te)), "median_rel_err": float(np.median(te)),
+                                   "worst_cell": {"cell": int(tidx[kt]), "species_index": ts[kt], "err": float(te[kt]),
+                                                  "reference_1e-8_vs_1e-10": float(tf[kt])},
+                                   "reference_1e-8_vs_1e-10_max": float(np.max(tf)), "reference_seconds": tdt}
+        return base, parity
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_ctypes as O
     onet = O.Network(os.path.join(DATA, network))
@@ -242,7 +311,8 @@ def main():
             cells_h = R.cells.andrews_grid(Md=2e-2 * (1.0 + rank / 16.0))
         wl = ("configs[2]: full synthetic Andrews-2009 grid, 200 columns x 100 cells = 20000 cell records (n_H 1e3..6e12 cm^-3, "
               "T 8..5000 K, per-cell t_max by the orbit rule), %s network (%s: %d species, %d reactions), %s, t_max0=%g yr, RTOL=%g, "
-              "steps_reset_solver=50" % (netkey, network, nS, net.nReactions, initial, params.t_max, params.RTOL))
+              "steps_reset_solver=50; every cell with the shielding factors of its record as given, i.e. frozen shielding (Jacobi relaxation "
+              "over global iterations), all cells in one batch" % (netkey, network, nS, net.nReactions, initial, params.t_max, params.RTOL))
     else:
         ncell0 = args.cells or 10000
         cells_h = R.cells.synth_batch(ncell0, seed=20240601 + rank)
@@ -338,14 +408,16 @@ def main():
         # FETCH_SIZE corrected by the factor measured with a micro-kernel of known bytes and the same 8 B/lane buffer loads)
         # times this launch's cell-steps: "calibrated, not measured".
         traffic, traffic_src = None, None
-        try:
-            cal = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_calibration.json")))
-            if cal["workload"]["name"] == args.workload and cal["workload"]["network"] == network:
-                traffic = cal["bytes_per_cell_step_corrected"] * nst
-                traffic_src = ("calibrated, not measured in this run: profiles/r2_pmc_calibration.json, %.0f B per cell-step x %d cell-steps"
-                               % (cal["bytes_per_cell_step_corrected"], int(nst)))
-        except Exception:
-            pass
+        for calname in ("r3_pmc_calibration.json", "r2_pmc_calibration.json"):
+            try:
+                cal = json.load(open(os.path.join(ROOT, "profiles", calname)))
+                if cal["workload"]["name"] == args.workload and cal["workload"]["network"] == network:
+                    traffic = cal["bytes_per_cell_step_corrected"] * nst
+                    traffic_src = ("calibrated, not measured in this run: profiles/%s, %.0f B per cell-step x %d cell-steps; TCC FETCH/WRITE "
+                                   "counters see what crosses L2, i.e. Infinity-Cache (MALL) hits as well as HBM" % (calname, cal["bytes_per_cell_step_corrected"], int(nst)))
+                    break
+            except Exception:
+                pass
         cyc = stats[:, R.S_CYC_TOTAL].astype(np.float64)
         out = {
             "metric": "cell-steps/s (whole node)", "value": steps_all / t_all, "unit": "cell-steps/s",
@@ -364,7 +436,11 @@ def main():
                        "queue_order_first_pass": ({"ms": 1e3 * first_pass_s, "cell_steps_per_s_rank0": float(stats[:, 0].sum()) / first_pass_s}
                                                   if (first_pass_s and hinted) else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # achieved / frac are ALGORITHMIC bytes over kernel time; traffic is what the counters saw crossing L2 for the same
+                         # launch, traffic_rate / traffic_frac_of_peak the same divided by the same kernel time
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_rate": (traffic / (kms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_peak": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          # one pass = k_solve (one wave per cell) followed by k_solve_team_resume (the cells handed over at its end),
                          # with k_solve_team (cells in teams from the start) alongside: timed as a whole between two HIP events
                          "kernel": "k_solve (+ k_solve_team, k_solve_team_resume)", "kernel_ms": kms,
@@ -384,7 +460,8 @@ def main():
             cores = min(os.cpu_count() or 1, 16)
             nsample = min(ncell, 16 * cores)
             sample_idx = np.arange(nsample) * (ncell // nsample) + (ncell // nsample) // 2  # spread over the whole batch
-            gpu = {"y": y_d.cpu().numpy(), "t_final": tfin_d.cpu().numpy(), "quality": qual, "nst": stats[:, 0], "nerr": stats[:, R.S_NERR]}
+            gpu = {"y": y_d.cpu().numpy(), "t_final": tfin_d.cpu().numpy(), "quality": qual, "nst": stats[:, 0], "nerr": stats[:, R.S_NERR],
+                   "errcodes": stats[:, R.S_ERRCODES]}
             tidx = sample_idx[::max(1, nsample // 32)][:32]
             p8 = R.default_params()
             for f in ("ATOL", "t_max", "dt_first_step", "ratio_tstep", "mxstep_per_interval", "steps_reset_solver"):
