@@ -12,6 +12,8 @@
 ! Output: plain-text vectors, one value per line, %ES25.17E3.
 program ref_driver
   use chemistry
+  use heating_cooling
+  use disk, only: a_disk
   use trivials, only: double2str
   implicit none
   external chem_ode_f, chem_ode_jac
@@ -27,9 +29,19 @@ program ref_driver
   double precision, allocatable :: flux(:)
   integer :: ie, isp, fA
   character(len=256) :: y_override
+  ! evolT = 1: gas temperature co-evolution (chemsol_params%evolT, src/disk.f90:2069-2073).  hc_file: one row of NHC numbers per
+  ! cell = the fields of the cell record that only the heating/cooling terms read (layout: include/racgpu.h, RACGPU_H_*);
+  ! enthalpy: the species-enthalpy file (chemical heating); transitions_dir: where the ion-cooling tables N+/Si+/Fe+_LUT.bin lie.
+  ! The heating/cooling switches are the README template's (README.md:135-156).
+  integer :: evolT, may_switch_T
+  character(len=256) :: hc_file, enthalpy, transitions_dir
+  integer, parameter :: NHC = 28
+  double precision :: hpar(NHC), Tdot
+  integer :: fH
   namelist /ref_run/ chem_dir, network, initial, out_dir, cell_file, ncell, &
     rtol, atol, dt_first_step, ratio_tstep, t_max, mxstep, steps_reset, h2_moeq, &
-    dump_jac, dump_record_every, solve, nlocal_iter, tol_j, y_override, special_gH_mobi, dump_analysis
+    dump_jac, dump_record_every, solve, nlocal_iter, tol_j, y_override, special_gH_mobi, dump_analysis, &
+    evolT, may_switch_T, hc_file, enthalpy, transitions_dir
   double precision, allocatable :: abund(:)
   double precision :: t_final, t_end, dt0, tmp, ov_val
   integer :: jj, isav, qual_cell, ov_cell, ov_spe, fO, ios
@@ -46,6 +58,7 @@ program ref_driver
   t_max = 1D6; mxstep = 6000; steps_reset = 50; h2_moeq = .false.
   dump_jac = 1; dump_record_every = 0; solve = 1
   nlocal_iter = 1; tol_j = 1; y_override = ''; special_gH_mobi = .false.; dump_analysis = 0
+  evolT = 0; may_switch_T = 1; hc_file = ''; enthalpy = ''; transitions_dir = './transitions/'
   open(newunit=fU, file=trim(nml_file), status='old', action='read')
   read(fU, nml=ref_run)
   close(fU)
@@ -53,7 +66,7 @@ program ref_driver
   chemsol_params%chem_files_dir = chem_dir
   chemsol_params%filename_chemical_network = network
   chemsol_params%filename_initial_abundances = initial
-  chemsol_params%filename_species_enthalpy = ''
+  chemsol_params%filename_species_enthalpy = enthalpy
   chemsol_params%RTOL = rtol
   chemsol_params%ATOL = atol
   chemsol_params%t0 = 0D0
@@ -80,6 +93,40 @@ program ref_driver
   call chem_prepare_solver_storage
   call chem_evol_solve_prepare_run_once
   call chem_load_initial_abundances
+  if (evolT .ne. 0) then
+    ! src/disk.f90:1573-1575 (enthalpies -> reaction heats), :1643 (hc_params => chem_params), heating_cooling_prepare
+    call chem_load_species_enthalpies
+    call chem_get_reaction_heat
+    heating_cooling_config%dir_transition_rates = transitions_dir
+    heating_cooling_config%use_analytical_CII_OI = .true.
+    heating_cooling_config%IonCoolingWithLut = .true.
+    heating_cooling_config%filename_NII = 'N+_LUT.bin'
+    heating_cooling_config%filename_SiII = 'Si+_LUT.bin'
+    heating_cooling_config%filename_FeII = 'Fe+_LUT.bin'
+    heating_cooling_config%solve_method = 2
+    heating_cooling_config%use_mygasgraincooling = .true.
+    heating_cooling_config%use_chemicalheatingcooling = .true.
+    heating_cooling_config%use_Xray_heating = .true.
+    heating_cooling_config%heating_Xray_en = 0D0
+    heating_cooling_config%heating_eff_chem = 0.3D0
+    heating_cooling_config%heating_eff_H2form = 0.5D0
+    heating_cooling_config%heating_eff_phd_H2 = 1D0
+    heating_cooling_config%heating_eff_phd_H2O = 0.5D0
+    heating_cooling_config%heating_eff_phd_OH = 0.5D0
+    heating_cooling_config%cooling_gg_coeff = 1D0
+    call heating_cooling_prepare
+    hc_params => chem_params
+    a_disk%allow_gas_dust_en_exch = .false.
+    a_disk%Tdust_iter_tandem = .false.
+    a_disk%base_alpha = 0.01D0
+    open(newunit=fH, file=trim(hc_file), status='old', action='read')
+    open(newunit=fC, file=trim(out_dir)//'/heat.txt', status='replace')
+    write(fC, '(I8)') chem_net%nReacWithHeat
+    do i = 1, chem_net%nReacWithHeat
+      write(fC, '(I8, ES25.17E3)') chem_net%iReacWithHeat(i), chem_net%heat(i)
+    end do
+    close(fC)
+  end if
 
   nS = chem_species%nSpecies
   NEQ = chemsol_params%NEQ
@@ -149,6 +196,26 @@ program ref_driver
     chem_params%f_selfshielding_toStar_CO = cpar(25)
     chem_params%f_selfshielding_toStar_H2O= cpar(26)
     chem_params%f_selfshielding_toStar_OH = cpar(27)
+    if (evolT .ne. 0) then
+      read(fH, *) hpar
+      chem_params%en_gain_tot     = hpar(1)
+      chem_params%Ncol_toStar     = hpar(2)
+      chem_params%PAH_abundance   = hpar(3)
+      chem_params%MeanMolWeight   = hpar(4)
+      chem_params%omega_Kepler    = hpar(5)
+      chem_params%velo_width_turb = hpar(6)
+      chem_params%coherent_length = hpar(7)
+      chem_params%Neufeld_G       = hpar(8)
+      chem_params%Neufeld_dv_dz   = hpar(9)
+      chem_params%dust_depletion  = hpar(10)
+      chem_params%volume          = hpar(11)
+      chem_params%ndustcompo      = int(hpar(12))
+      chem_params%sig_dusts       = hpar(13:16)
+      chem_params%n_dusts         = hpar(17:20)
+      chem_params%Tdusts          = hpar(21:24)
+      chem_params%en_gains        = hpar(25:28)
+      chem_params%X_gH            = 0D0
+    end if
 
     ! src/disk.f90:2055-2075 (set_initial_condition_4solver), fixed-T branch.
     chemsol_stor%y(1:nS) = chemsol_stor%y0(1:nS)
@@ -167,6 +234,11 @@ program ref_driver
     end if
     chemsol_params%evolT = .false.
     chemsol_params%maySwitchT = .false.
+    if (evolT .ne. 0) then ! src/disk.f90:2069-2073
+      chemsol_params%evolT = .true.
+      chemsol_params%maySwitchT = may_switch_T .ne. 0
+      if (chem_params%en_gain_tot .le. 0D0) chemsol_params%evolT = .false.
+    end if
     chemsol_params%t0 = 0D0
     chemsol_params%dt_first_step = dt_first_step
     chemsol_params%t_max = t_max
@@ -196,6 +268,7 @@ program ref_driver
     do i = 1, NEQ
       write(fC, '(ES25.17E3)') ydot(i)
     end do
+    if (evolT .ne. 0) call dump_hc(fC, 'hc0 ')
     if (dump_jac .ne. 0) then
       write(fC, '(A, I8)') '# jac0 ', chemsol_params%NNZ
       do j = 1, NEQ
@@ -365,8 +438,60 @@ program ref_driver
       do i = 1, NEQ
         write(fC, '(ES25.17E3)') ydot(i)
       end do
+      if (evolT .ne. 0) then
+        call dump_hc(fC, 'hcend ')
+        write(fC, '(A, I8)') '# Trecord ', chemsol_params%n_record
+        do i = 1, chemsol_params%n_record
+          write(fC, '(ES25.17E3)') chemsol_stor%record(nS + 1, i)
+        end do
+        write(fC, '(A, I8)') '# evolTend ', 1  ! 1: T was still evolving at the end of the run, 0: the T-freeze test switched it off
+        if (chemsol_params%evolT) then
+          write(fC, '(ES25.17E3)') 1D0
+        else
+          write(fC, '(ES25.17E3)') 0D0
+        end if
+      end if
     end if
     close(fC)
   end do
   close(fU)
+contains
+  subroutine dump_hc(fC, tag)
+    ! the 28 heating/cooling terms of the last chem_ode_f call (heating_minus_cooling, src/heating_cooling.f90:1204-1269), erg s-1 cm-3,
+    ! in the order of type_heating_cooling_rates_list (src/data_struct.f90:489-520): net first
+    integer, intent(in) :: fC
+    character(len=*), intent(in) :: tag
+    write(fC, '(A, A, I8)') '# ', tag, 29
+    associate(r => heating_cooling_rates)
+      write(fC, '(ES25.17E3)') r%hc_net_rate
+      write(fC, '(ES25.17E3)') r%heating_photoelectric_small_grain_rate
+      write(fC, '(ES25.17E3)') r%heating_formation_H2_rate
+      write(fC, '(ES25.17E3)') r%heating_cosmic_ray_rate
+      write(fC, '(ES25.17E3)') r%heating_vibrational_H2_rate
+      write(fC, '(ES25.17E3)') r%heating_ionization_CI_rate
+      write(fC, '(ES25.17E3)') r%heating_photodissociation_H2_rate
+      write(fC, '(ES25.17E3)') r%heating_photodissociation_H2O_rate
+      write(fC, '(ES25.17E3)') r%heating_photodissociation_OH_rate
+      write(fC, '(ES25.17E3)') r%heating_Xray_Bethell_rate
+      write(fC, '(ES25.17E3)') r%heating_viscosity_rate
+      write(fC, '(ES25.17E3)') r%heating_chem
+      write(fC, '(ES25.17E3)') r%cooling_photoelectric_small_grain_rate
+      write(fC, '(ES25.17E3)') r%cooling_vibrational_H2_rate
+      write(fC, '(ES25.17E3)') r%cooling_gas_grain_collision_rate
+      write(fC, '(ES25.17E3)') r%cooling_OI_rate
+      write(fC, '(ES25.17E3)') r%cooling_CII_rate
+      write(fC, '(ES25.17E3)') r%cooling_Neufeld_H2O_rate_rot
+      write(fC, '(ES25.17E3)') r%cooling_Neufeld_H2O_rate_vib
+      write(fC, '(ES25.17E3)') r%cooling_Neufeld_CO_rate_rot
+      write(fC, '(ES25.17E3)') r%cooling_Neufeld_CO_rate_vib
+      write(fC, '(ES25.17E3)') r%cooling_Neufeld_H2_rot_rate
+      write(fC, '(ES25.17E3)') r%cooling_LymanAlpha_rate
+      write(fC, '(ES25.17E3)') r%cooling_free_bound_rate
+      write(fC, '(ES25.17E3)') r%cooling_free_free_rate
+      write(fC, '(ES25.17E3)') r%cooling_NII_rate
+      write(fC, '(ES25.17E3)') r%cooling_SiII_rate
+      write(fC, '(ES25.17E3)') r%cooling_FeII_rate
+      write(fC, '(ES25.17E3)') r%cooling_OH_rot_rate
+    end associate
+  end subroutine dump_hc
 end program ref_driver
