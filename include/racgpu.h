@@ -89,13 +89,17 @@ enum { RACGPU_S_NST = 0, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_NERR
                             src/chemistry.f90:272-387) */ };
 
 /* per-cell values the path writes back into the cell record (double x RACGPU_NOUT per cell) */
-#define RACGPU_NOUT 3
+#define RACGPU_NOUT 5
 enum { RACGPU_O_R_H2_FORM = 0,     /* chem_params%R_H2_form_rate_coeff [s^-1] (src/chemistry.f90:804,891); untouched if the network
                                       has no H2-formation reaction */
        RACGPU_O_N_MOL_ON_GRAIN,    /* chem_params%n_mol_on_grain: get_ice_coverage's side effect on the handed-back abundances
                                       (src/chemistry.f90:989-1003, src/disk.f90:1736); untouched when isav <= 1 */
-       RACGPU_O_T_END };           /* touts(n_record_real): where the integration itself stopped (>= t_final when the tail of the
+       RACGPU_O_T_END,             /* touts(n_record_real): where the integration itself stopped (>= t_final when the tail of the
                                       record held NaNs) */
+       RACGPU_O_TGAS,              /* c%par%Tgas = record(nSpecies+1, isav) (src/disk.f90:1732): the gas temperature of the hand-off
+                                      record; the record's own Tgas when T is not evolving; untouched when isav <= 1 */
+       RACGPU_O_EVOLT_END };       /* racgpu_evolT_solve_batch: 1 if T was still evolving at the end of the run, 0 if the T-freeze test
+                                      (src/chemistry.f90:532-546) or en_gain_tot <= 0 had switched it off */
 
 /* flags of racgpu_evol_solve_batch */
 #define RACGPU_F_RECTIFY 1 /* apply rectify_abundances (src/chemistry.f90:2170-2201) to y before integrating: the continue path */
@@ -186,6 +190,59 @@ int racgpu_solve_batch(racgpu_network *, const racgpu_params *, int64_t ncell, c
 int racgpu_evol_solve_batch(racgpu_network *, const racgpu_params *, int64_t ncell, const double *cells, double *y,
                             const double *t0, const int32_t *tol_j, double *t_final, int32_t *quality, int64_t *stats,
                             double *record, double *touts, double *cell_out, int flags, int mem);
+/* ---- gas temperature co-evolving with the chemistry: chemsol_params%evolT (set_initial_condition_4solver, src/disk.f90:2066-2073:
+ * T evolves in every cell with en_gain_tot > 0).  NEQ = nS + 1: the last unknown is Tgas, its derivative the net of the 11 heating
+ * and 17 cooling terms (realtime_heating_cooling_rate, src/disk.f90:4664-4741; heating_minus_cooling, src/heating_cooling.f90:1204-1269),
+ * the rate coefficients are recomputed at the iterate's T before every chem_ode_f, the T row and column of the Jacobian come from
+ * finite differences (src/disk.f90:4878-4899), and once T has settled the run goes on with T fixed (src/chemistry.f90:532-546).
+ * Implemented for the reference's default switches: use_analytical_CII_OI = IonCoolingWithLut = .true., dust_gas_linear_couple =
+ * .false., no tandem dust-temperature iteration (a_disk%allow_gas_dust_en_exch / Tdust_iter_tandem = .false.). */
+/* the fields of the cell record (type_cell_rz_phy_basic, src/data_struct.f90:316-442) that only the heating/cooling terms read */
+#define RACGPU_NHC 28
+enum {
+  RACGPU_H_EN_GAIN_TOT = 0,  /* en_gain_tot: > 0 switches T evolution on for the cell (src/disk.f90:2071)        */
+  RACGPU_H_NCOL_STAR,        /* Ncol_toStar                [cm^-2]                                                */
+  RACGPU_H_PAH,              /* PAH_abundance                                                                     */
+  RACGPU_H_MMW,              /* MeanMolWeight                                                                     */
+  RACGPU_H_OMEGA_K,          /* omega_Kepler               [s^-1]                                                 */
+  RACGPU_H_DV_TURB,          /* velo_width_turb            [cm s^-1]                                              */
+  RACGPU_H_COHERENT,         /* coherent_length            [cm]                                                   */
+  RACGPU_H_NEUFELD_G,        /* Neufeld_G                                                                         */
+  RACGPU_H_NEUFELD_DVDZ,     /* Neufeld_dv_dz              [km s^-1 cm^-1]                                        */
+  RACGPU_H_DUST_DEPL,        /* dust_depletion (only with use_mygasgraincooling = 0)                              */
+  RACGPU_H_VOLUME,           /* volume                     [cm^3]                                                 */
+  RACGPU_H_NDUSTCOMPO,       /* ndustcompo (1..4), then four slots each of:                                       */
+  RACGPU_H_SIG_DUSTS,        /* sig_dusts(1:4)             [cm^2]                                                 */
+  RACGPU_H_N_DUSTS = RACGPU_H_SIG_DUSTS + 4,  /* n_dusts(1:4)   [cm^-3]                                           */
+  RACGPU_H_TDUSTS = RACGPU_H_N_DUSTS + 4,     /* Tdusts(1:4)    [K]                                               */
+  RACGPU_H_EN_GAINS = RACGPU_H_TDUSTS + 4     /* en_gains(1:4)  [erg s^-1] (caps what the dust can give back)     */
+};
+/* heating_cooling_config (src/heating_cooling.f90:16-38) as far as these branches read it, a_disk%base_alpha (src/disk.f90:32) and
+ * chemsol_params%maySwitchT (src/disk.f90:2070) */
+typedef struct racgpu_hc_config {
+  double heating_eff_chem, heating_eff_H2form, heating_eff_phd_H2, heating_eff_phd_H2O, heating_eff_phd_OH, cooling_gg_coeff, base_alpha;
+  int32_t use_chemicalheatingcooling, use_Xray_heating, use_phdheating_H2, use_phdheating_H2OOH, use_mygasgraincooling, may_switch_T;
+} racgpu_hc_config;
+void racgpu_hc_config_default(racgpu_hc_config *); /* the reference's template (README.md:135-156) */
+/* heating_cooling_prepare + chem_load_species_enthalpies + chem_get_reaction_heat (src/heating_cooling.f90:68-102, src/chemistry.f90:2027-2146):
+ * the species-enthalpy file, the Neufeld cooling tables (data/neufeld_cooling_tables.dat: compiled into the reference) and the three ion
+ * line-cooling tables N+ / Si+ / Fe+ _LUT.bin.  Host only. */
+int racgpu_heating_cooling_load(racgpu_network *, const racgpu_hc_config *, const char *enthalpy_file, const char *neufeld_tables,
+                                const char *nii_lut, const char *siii_lut, const char *feii_lut);
+/* chem_net%nReacWithHeat, %iReacWithHeat (1-based), %heat [erg] as chem_get_reaction_heat builds them; any pointer may be NULL */
+int racgpu_heat_reactions(const racgpu_network *, int32_t *n, int32_t *rxn, double *heat);
+/* the 29 values of type_heating_cooling_rates_list in its order (src/data_struct.f90:489-520: the net rate, 11 heating, 17 cooling terms) */
+#define RACGPU_NHCTERMS 29
+/* test hooks (host buffers): chem_ode_f with T evolving at y [ncell*(nS+1)] (last entry = Tgas) -> ydot [ncell*(nS+1)] and the terms
+ * [ncell*RACGPU_NHCTERMS, erg s^-1 cm^-3] behind its last entry; with tcol/trow also chem_ode_jac's finite-difference T column
+ * [ncell*(nS+1)] and T row [ncell*10: at H2, H, E-, C, C+, O, O2, CO, H2O, OH] */
+int racgpu_evolT_hooks(racgpu_network *, const racgpu_params *, const double *cells, const double *hc, int64_t ncell, const double *y,
+                       double *ydot, double *terms, double *tcol, double *trow);
+/* racgpu_evol_solve_batch with T evolving: hc [ncell*RACGPU_NHC]; the cell record's Tgas is the initial temperature, cell_out
+ * [RACGPU_O_TGAS] the temperature handed back, record's last slot T(t).  One wave per cell. */
+int racgpu_evolT_solve_batch(racgpu_network *, const racgpu_params *, int64_t ncell, const double *cells, const double *hc, double *y,
+                             const double *t0, const int32_t *tol_j, double *t_final, int32_t *quality, int64_t *stats, double *record,
+                             double *touts, double *cell_out, int flags, int mem);
 /* calc_this_cell's chemistry for a batch (src/disk.f90:1651-1791): up to nlocal_iter local iterations per cell.  Iteration 1
  * integrates every cell from t = 0 with chem_set_solver_flags_alt(1).  A cell whose run ended with quality != 0 before half
  * of its t_max goes into iteration j = 2, 3, ...: abundances of the hand-off record, rectify_abundances, t0 = t_final,

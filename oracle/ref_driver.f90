@@ -123,7 +123,7 @@ program ref_driver
     open(newunit=fC, file=trim(out_dir)//'/heat.txt', status='replace')
     write(fC, '(I8)') chem_net%nReacWithHeat
     do i = 1, chem_net%nReacWithHeat
-      write(fC, '(I8, ES25.17E3)') chem_net%iReacWithHeat(i), chem_net%heat(i)
+      write(fC, '(I8, X, ES25.17E3)') chem_net%iReacWithHeat(i), chem_net%heat(i)
     end do
     close(fC)
   end if
@@ -432,7 +432,17 @@ program ref_driver
         end do
         close(fA)
       end if
-      ! RHS at the end state: second ydot pin, at a chemically evolved composition.
+      ! RHS at the end state: second ydot pin, at a chemically evolved composition (with T evolving again if the T-freeze test had
+      ! switched it off: the dump is of chem_ode_f's evolT branch)
+      if ((evolT .ne. 0) .and. (chem_params%en_gain_tot .gt. 0D0)) then
+        write(fC, '(A, I8)') '# evolTend ', 1  ! 1: T was still evolving at the end of the run, 0: the T-freeze test had switched it off
+        if (chemsol_params%evolT) then
+          write(fC, '(ES25.17E3)') 1D0
+        else
+          write(fC, '(ES25.17E3)') 0D0
+        end if
+        chemsol_params%evolT = .true.
+      end if
       call chem_ode_f(NEQ, tdummy, chemsol_stor%y, ydot)
       write(fC, '(A, I8)') '# ydotend ', NEQ
       do i = 1, NEQ
@@ -444,12 +454,6 @@ program ref_driver
         do i = 1, chemsol_params%n_record
           write(fC, '(ES25.17E3)') chemsol_stor%record(nS + 1, i)
         end do
-        write(fC, '(A, I8)') '# evolTend ', 1  ! 1: T was still evolving at the end of the run, 0: the T-freeze test switched it off
-        if (chemsol_params%evolT) then
-          write(fC, '(ES25.17E3)') 1D0
-        else
-          write(fC, '(ES25.17E3)') 0D0
-        end if
       end if
     end if
     close(fC)

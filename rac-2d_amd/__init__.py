@@ -23,12 +23,21 @@ from .cells import NPAR
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RACGPU_LIB") or os.path.join(_HERE, "libracgpu.so")  # RACGPU_LIB: developer builds
 NSTAT = 20
-NOUT = 3
+NOUT = 5
+NHC = 28
+NHCTERMS = 29
 MEM_HOST, MEM_DEVICE = 0, 1
 F_RECTIFY = 1
 (S_NST, S_NFE, S_NJE, S_NLU, S_NERR, S_NREC_REAL, S_QSUM, S_NCFAIL_ETFAIL, S_CYC_TOTAL, S_CYC_RHS, S_CYC_JAC, S_CYC_LU,
  S_CYC_SOLVE, S_CYC_LU_SCATTER, S_CYC_LU_LDS, S_CYC_LU_REG, S_ISAV, S_NITER, S_NREC, S_ERRCODES) = range(NSTAT)
-O_R_H2_FORM, O_N_MOL_ON_GRAIN, O_T_END = range(NOUT)
+O_R_H2_FORM, O_N_MOL_ON_GRAIN, O_T_END, O_TGAS, O_EVOLT_END = range(NOUT)
+# the 29 values of type_heating_cooling_rates_list, in its order (reference src/data_struct.f90:489-520)
+HC_TERM_NAMES = ("hc_net_rate", "heating_photoelectric_small_grain", "heating_formation_H2", "heating_cosmic_ray", "heating_vibrational_H2",
+                 "heating_ionization_CI", "heating_photodissociation_H2", "heating_photodissociation_H2O", "heating_photodissociation_OH",
+                 "heating_Xray_Bethell", "heating_viscosity", "heating_chem", "cooling_photoelectric_small_grain", "cooling_vibrational_H2",
+                 "cooling_gas_grain_collision", "cooling_OI", "cooling_CII", "cooling_Neufeld_H2O_rot", "cooling_Neufeld_H2O_vib",
+                 "cooling_Neufeld_CO_rot", "cooling_Neufeld_CO_vib", "cooling_Neufeld_H2_rot", "cooling_LymanAlpha", "cooling_free_bound",
+                 "cooling_free_free", "cooling_NII", "cooling_SiII", "cooling_FeII", "cooling_OH_rot")
 
 # every extern "C" symbol include/racgpu.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
@@ -38,6 +47,7 @@ ABI_SYMBOLS = [
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
     "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_column_sweep", "racgpu_set_co_shielding_table", "racgpu_rectify_abundances",
+    "racgpu_hc_config_default", "racgpu_heating_cooling_load", "racgpu_heat_reactions", "racgpu_evolT_hooks", "racgpu_evolT_solve_batch",
     "racgpu_set_cost_hints", "racgpu_set_team_threshold", "racgpu_last_team_cells", "racgpu_last_parked_cells", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
 ]
 
@@ -54,6 +64,16 @@ class ChemsolParams(C.Structure):
         ("max_steps_per_cell", C.c_int64),
         ("rt_cost_f", C.c_double), ("rt_cost_jac", C.c_double), ("rt_cost_lu", C.c_double),
     ]
+
+
+class HcConfig(C.Structure):
+    """``racgpu_hc_config``: heating_cooling_config (reference src/heating_cooling.f90:16-38) as far as the implemented branches read it,
+    a_disk%base_alpha and chemsol_params%maySwitchT."""
+    _fields_ = [("heating_eff_chem", C.c_double), ("heating_eff_H2form", C.c_double), ("heating_eff_phd_H2", C.c_double),
+                ("heating_eff_phd_H2O", C.c_double), ("heating_eff_phd_OH", C.c_double), ("cooling_gg_coeff", C.c_double),
+                ("base_alpha", C.c_double),
+                ("use_chemicalheatingcooling", C.c_int32), ("use_Xray_heating", C.c_int32), ("use_phdheating_H2", C.c_int32),
+                ("use_phdheating_H2OOH", C.c_int32), ("use_mygasgraincooling", C.c_int32), ("may_switch_T", C.c_int32)]
 
 
 _lib = None
@@ -117,6 +137,12 @@ def lib():
     L.racgpu_column_sweep.argtypes = [vp, C.POINTER(ChemsolParams), C.c_int64, vp, vp, C.c_int64, vp, vp, vp, C.c_double, vp, vp, vp, vp, C.c_int]
     L.racgpu_set_co_shielding_table.restype = C.c_int
     L.racgpu_set_co_shielding_table.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
+    L.racgpu_hc_config_default.argtypes = [C.POINTER(HcConfig)]
+    L.racgpu_hc_config_default.restype = None
+    L.racgpu_heating_cooling_load.argtypes = [vp, C.POINTER(HcConfig), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.racgpu_heat_reactions.argtypes = [vp, ip, ip, dp]
+    L.racgpu_evolT_hooks.argtypes = [vp, pp, dp, dp, C.c_int64, dp, dp, dp, vp, vp]
+    L.racgpu_evolT_solve_batch.argtypes = [vp, pp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int]
     L.racgpu_set_team_threshold.restype = C.c_int
     L.racgpu_set_team_threshold.argtypes = [vp, C.c_double]
     L.racgpu_last_team_cells.restype = C.c_int64
@@ -148,6 +174,12 @@ def default_params():
     p = ChemsolParams()
     lib().racgpu_params_default(C.byref(p))
     return p
+
+
+def default_hc_config():
+    c = HcConfig()
+    lib().racgpu_hc_config_default(C.byref(c))
+    return c
 
 
 def device_count():
@@ -302,6 +334,61 @@ class Network:
                                              tos.ctypes.data if record else None, co.ctypes.data, F_RECTIFY if rectify else 0, MEM_HOST))
         return dict(y=y, t_final=tf, quality=q, stats=st, record=rec, touts=tos, cell_out=co,
                     kernel_ms=lib().racgpu_last_kernel_ms(self._h))
+
+    # ---- gas temperature co-evolving with the chemistry (chemsol_params%evolT) -------------------------------------------------
+    def load_heating_cooling(self, data_dir, config=None):
+        """heating_cooling_prepare + the reaction heats: reads Species_enthalpy.dat, neufeld_cooling_tables.dat and the three ion
+        look-up tables from data_dir (data/README.md).  config: an HcConfig (default: the reference's template values)."""
+        cfg = config or default_hc_config()
+        j = lambda f: os.fsencode(os.path.join(data_dir, f))
+        _check(lib().racgpu_heating_cooling_load(self._h, C.byref(cfg), j("Species_enthalpy.dat"), j("neufeld_cooling_tables.dat"),
+                                                 j("N+_LUT.bin"), j("Si+_LUT.bin"), j("Fe+_LUT.bin")))
+
+    def heat_reactions(self):
+        """chem_net%iReacWithHeat (1-based) and %heat [erg] (chem_get_reaction_heat)."""
+        n = C.c_int32()
+        _check(lib().racgpu_heat_reactions(self._h, C.byref(n), None, None))
+        rx = np.zeros(n.value, np.int32); ht = np.zeros(n.value)
+        _check(lib().racgpu_heat_reactions(self._h, C.byref(n), _ip(rx), _dp(ht)))
+        return rx, ht
+
+    def ode_f_evolT(self, params, cell_records, hc_records, y, jac_border=False):
+        """chem_ode_f with T evolving at y [ncell, nS+1] (last entry Tgas): dict(ydot [ncell, nS+1], terms [ncell, 29]); with
+        jac_border also chem_ode_jac's finite-difference T column [ncell, nS+1] and T row [ncell, 10]."""
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        n = cr.shape[0]
+        hr = np.ascontiguousarray(hc_records, np.float64).reshape(n, NHC)
+        y = np.ascontiguousarray(y, np.float64).reshape(n, self.nSpecies + 1)
+        yd = np.zeros_like(y); tm = np.zeros((n, NHCTERMS))
+        tc = np.zeros_like(y) if jac_border else None
+        tr = np.zeros((n, 10)) if jac_border else None
+        _check(lib().racgpu_evolT_hooks(self._h, C.byref(params), _dp(cr), _dp(hr), n, _dp(y), _dp(yd), _dp(tm),
+                                        tc.ctypes.data if jac_border else None, tr.ctypes.data if jac_border else None))
+        return dict(ydot=yd, terms=tm, tcol=tc, trow=tr)
+
+    def evolT_solve_batch(self, params, cell_records, hc_records, y, record=False, t0=None, tol_j=None, rectify=False):
+        """evol_solve_batch with the gas temperature co-evolving in every cell whose hc record has en_gain_tot > 0; the cell record's
+        Tgas is the initial temperature, cell_out[:, O_TGAS] the one handed back, record[..., nS] T(t)."""
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        n = cr.shape[0]
+        hr = np.ascontiguousarray(hc_records, np.float64).reshape(n, NHC)
+        y = np.array(y, np.float64).reshape(n, self.nSpecies).copy()
+        tf = np.zeros(n); q = np.zeros(n, np.int32); st = np.zeros((n, NSTAT), np.int64); co = np.full((n, NOUT), np.nan)
+        t0a = None if t0 is None else np.ascontiguousarray(np.broadcast_to(np.asarray(t0, np.float64), (n,)))
+        tja = None if tol_j is None else np.ascontiguousarray(np.broadcast_to(np.asarray(tol_j, np.int32), (n,)))
+        rec = tos = None
+        if record:
+            nrec = lib().racgpu_n_record(C.byref(params), 0.0, params.t_max)
+            rec = np.zeros((n, nrec, self.nSpecies + 1)); tos = np.zeros((n, nrec))
+        _check(lib().racgpu_evolT_solve_batch(self._h, C.byref(params), n, cr.ctypes.data, hr.ctypes.data, y.ctypes.data,
+                                              None if t0a is None else t0a.ctypes.data, None if tja is None else tja.ctypes.data,
+                                              tf.ctypes.data, q.ctypes.data, st.ctypes.data, rec.ctypes.data if record else None,
+                                              tos.ctypes.data if record else None, co.ctypes.data, F_RECTIFY if rectify else 0, MEM_HOST))
+        return dict(y=y, t_final=tf, quality=q, stats=st, record=rec, touts=tos, cell_out=co, kernel_ms=lib().racgpu_last_kernel_ms(self._h))
+
+    def evolT_solve_batch_device(self, params, ncell, cells_ptr, hc_ptr, y_ptr, t_final_ptr=None, quality_ptr=None, stats_ptr=None, cell_out_ptr=None):
+        _check(lib().racgpu_evolT_solve_batch(self._h, C.byref(params), ncell, cells_ptr, hc_ptr, y_ptr, None, None, t_final_ptr, quality_ptr,
+                                              stats_ptr, None, None, cell_out_ptr, 0, MEM_DEVICE))
 
     def calc_cells(self, params, cell_records, y, nlocal_iter=4):
         """calc_this_cell's chemistry for every cell (reference src/disk.f90:1651-1791): up to nlocal_iter local iterations,

@@ -168,6 +168,48 @@ def andrews_grid(ncol=200, nz=100, rmin=0.1, rmax=200.0, zr_max=0.6, star_mass_m
 
 
 # ---------------------------------------------------------------------------------------------------------
+# The fields only the heating/cooling terms read (gas temperature co-evolving, evolT): racgpu.h RACGPU_H_*
+# ---------------------------------------------------------------------------------------------------------
+NHC = 28
+(H_EN_GAIN_TOT, H_NCOL_STAR, H_PAH, H_MMW, H_OMEGA_K, H_DV_TURB, H_COHERENT, H_NEUFELD_G, H_NEUFELD_DVDZ, H_DUST_DEPL, H_VOLUME,
+ H_NDUSTCOMPO) = range(12)
+H_SIG_DUSTS, H_N_DUSTS, H_TDUSTS, H_EN_GAINS = 12, 16, 20, 24
+
+
+def make_hc_record(cell, omega_kepler=2e-9, coherent_length=1e13, dv_turb=1e4, volume=1e39, en_gain=1e30, pah=1.6e-7):
+    """One heating/cooling record to go with a cell record: a single dust component that IS the cell's dust (sig_dusts =
+    sigdust_ave, n_dusts = ndust_tot, Tdusts = Tdust), Ncol_toStar from Av_toStar (5.3e-22 mag cm^2), ISM PAH abundance, mean
+    molecular weight 1.4, Neufeld G = 1 and dv/dz = omega_Kepler in km s^-1 cm^-1, en_gain_tot > 0 (T evolves)."""
+    cell = np.asarray(cell, dtype=np.float64)
+    h = np.zeros(cell.shape[:-1] + (NHC,))
+    h[..., H_EN_GAIN_TOT] = en_gain
+    h[..., H_NCOL_STAR] = cell[..., P_AV_STAR] / 5.3e-22
+    h[..., H_PAH] = pah; h[..., H_MMW] = 1.4; h[..., H_OMEGA_K] = omega_kepler; h[..., H_DV_TURB] = dv_turb
+    h[..., H_COHERENT] = coherent_length; h[..., H_NEUFELD_G] = 1.0; h[..., H_NEUFELD_DVDZ] = np.asarray(omega_kepler) * 1e-5
+    h[..., H_DUST_DEPL] = 1.0; h[..., H_VOLUME] = volume; h[..., H_NDUSTCOMPO] = 1.0
+    h[..., H_SIG_DUSTS] = cell[..., P_SIGDUST]; h[..., H_N_DUSTS] = cell[..., P_NDUST]; h[..., H_TDUSTS] = cell[..., P_TDUST]
+    h[..., H_EN_GAINS] = en_gain
+    return h
+
+
+def andrews_grid_hc(cells, r_au, z_au, star_mass_msun=0.6, nz=100, zr_max=0.6):
+    """Heating/cooling records for andrews_grid(return_geometry=True), again STATED CLOSED FORMS in place of what the reference's
+    Monte-Carlo radiative transfer and grid would supply: omega_Kepler from r; coherent length = the gas scale height h(r) = r/8;
+    turbulent width 0.1 of the isothermal sound speed at Tdust; cell volume 2 pi r dr dz of the log-spaced grid; the dust's energy
+    gain = sigma_SB Tdust^4 emission balance, 4 sig_dust n_dust sigma_SB Tdust^4 V (what the cap of the gas-grain term is measured
+    against); one dust component; ISM PAH abundance scaled down by 0.1 (settled disk)."""
+    cells = np.asarray(cells, dtype=np.float64)
+    r = np.asarray(r_au, dtype=np.float64) * AU_CM
+    omega = np.sqrt(G_CGS * star_mass_msun * MSUN_CGS / r ** 3)
+    cs = np.sqrt(1.3806503e-16 * cells[:, P_TDUST] / (1.4 * MP_CGS))
+    ncol = 200
+    dlnr = math.log(200.0 / 0.1) / ncol
+    vol = 2.0 * math.pi * r * (r * dlnr) * (r * zr_max / nz)
+    gain = 4.0 * cells[:, P_SIGDUST] * cells[:, P_NDUST] * 5.670373e-5 * cells[:, P_TDUST] ** 4 * vol
+    return make_hc_record(cells, omega_kepler=omega, coherent_length=r / 8.0, dv_turb=0.1 * cs, volume=vol, en_gain=gain, pah=1.6e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # Self-shielding factors of a cell from the column densities above it: the part of the caller's update_params_above_alt
 # (reference src/disk.f90:1823-1883) that only needs numbers, for sweeps that refresh the records of a layer from the layers
 # solved before it (sweep.solve_by_layers).  The column densities themselves come from the caller's grid (the reference traces

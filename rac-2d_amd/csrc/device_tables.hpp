@@ -113,6 +113,7 @@ struct DevWork { // per-cell workspace, all f64, cell-major
   double *rtol, *atol; // [ncell][npad]
   double *acor, *ewt; // [ncell][npad] accumulated correction and inverse error weights of the step in progress
   double *ygood;   // [ncell][npad] the last record whose T and H2 entries are not NaN (the hand-off record)
+  double *Pb, *zb; // [ncell][npad] evolT: the T column of P and (species block)^-1 times it
   double *park;    // [nslots][128 + npad] parked cells (engine_integrate.hpp, struct Parked, then the iterate), or null
   int *counter;    // [0] work queue head; further words: see solve_pass
   double *trace;   // developer aid: [debug_max_calls][8] step log of cell 0, or null

@@ -17,6 +17,7 @@
 
 #include "../../include/racgpu.h"
 #include "engine_integrate.hpp"
+#include "hc_tables.hpp"
 #include "network.hpp"
 
 using namespace racgpu;
@@ -101,6 +102,39 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   }
 }
 
+// Test hooks of the evolT path (host buffers): what = 0: chem_ode_f with T evolving (ydot incl. dT/dt) and the 29 heating/cooling
+// values behind it; what = 1: additionally the finite-difference T row and T column of chem_ode_jac (con = 1: plain J entries).
+__global__ __launch_bounds__(64) void k_evolT_hooks(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, const DevHC *hc_tab, const double *cells,
+                                                    const double *hc, const double *yin /* [ncell][nS+1] */, int what, double *ydot_out /* [ncell][nS+1] */,
+                                                    double *terms_out /* [ncell][HC_NTERMS] */, double *tcol_out /* [ncell][nS+1] */, double *trow_out /* [ncell][10] */) {
+  const DevNet &N = *Np; const DevParams &P = *Pp;
+  extern __shared__ double lds[];
+  const int cell = blockIdx.x, lane = threadIdx.x, n = N.nS, nlds = (n + 1) & ~1;
+  LdsViews v = carve(lds, nlds);
+  CellCtx c{};
+  c.y = v.y; c.savf = v.savf; c.wx = v.wx; c.lane = lane; c.n = n; c.npad = N.npad; c.nteam = 1;
+  c.rates = W.rates + (size_t)cell * N.nR; c.Pb = W.Pb + (size_t)cell * N.npad;
+  c.cell = cells + (size_t)cell * RACGPU_NPAR; c.hcrec = hc + (size_t)cell * kNHC; c.hc = hc_tab; c.prm = &P;
+  g_wc.nsite = c.cell[RACGPU_P_D2H] * c.cell[RACGPU_P_SITES];
+  const double *yc = yin + (size_t)cell * (n + 1);
+  for (int i = lane; i < n; i += 64) c.y[i] = yc[i];
+  g_T.y = yc[n]; g_T.evolT = 1;
+  wave_sync();
+  dev_f<true>(N, c, c.savf);
+  for (int i = lane; i < n; i += 64) ydot_out[(size_t)cell * (n + 1) + i] = c.savf[i];
+  if (lane == 0) ydot_out[(size_t)cell * (n + 1) + n] = g_T.savf;
+  // the terms once more, this time stored (same inputs: the rate vector is the one dev_f has just computed)
+  dev_heating_cooling(N, *(const RG_GLOBAL DevHC *)hc_tab, c.cell, c.hcrec, c.y, g_T.y, c.rates, g_T.rh2, lane, terms_out + (size_t)cell * HC_NTERMS);
+  if (what == 1) {
+    dev_T_border(N, c, 1.0);
+    for (int i = lane; i < n; i += 64) tcol_out[(size_t)cell * (n + 1) + i] = c.Pb[i];
+    if (lane == 0) {
+      tcol_out[(size_t)cell * (n + 1) + n] = g_T.Pd - 1.0;
+      for (int k = 0; k < 10; ++k) trow_out[(size_t)cell * 10 + k] = g_T.Pc[k];
+    }
+  }
+}
+
 // The hot path.  Persistent: each wave pulls cells from a queue until it is empty; its workspace is per wave
 // (slot), not per cell, so the HBM footprint is nslots * ~0.4 MB whatever the batch size.
 struct SolveArgs {
@@ -124,6 +158,8 @@ struct SolveArgs {
   const double *dz;                 // [ncell] path length through the cell towards the surface [cm]
   double dv_turb;                   // turbulent line width [cm/s] of the H2 self-shielding formula
   double *cells_rw;                 // = cells
+  // k_solve_T (gas temperature co-evolving): the cells' heating/cooling records [ncell][RACGPU_NHC] and the tables
+  const double *hc; const DevHC *hc_tab;
 };
 constexpr int kParkWords = 128;     // doubles reserved per slot for struct Parked (in front of the parked iterate)
 static_assert(sizeof(Parked) <= kParkWords * sizeof(double), "Parked outgrew its slot");
@@ -136,8 +172,9 @@ static_assert(sizeof(Parked) <= kParkWords * sizeof(double), "Parked outgrew its
 struct ColumnAcc { double N_H2, N_H2O, N_OH, N_CO; };
 static __shared__ volatile ColumnAcc g_col;
 
-template <int TEAM, bool RESUME, bool COLUMN = false>
+template <int TEAM, bool RESUME, bool COLUMN = false, bool ET = false>
 RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, const SolveArgs &A, double *lds) {
+  static_assert(!ET || (TEAM == 1 && !RESUME && !COLUMN), "the evolT kernel is one wave per cell");
   const int lane = threadIdx.x & 63, wv = TEAM > 1 ? uniform_i((int)(threadIdx.x >> 6)) : 0;
   const int n = N.nS, nlds = (n + 1) & ~1;
   LdsViews v = carve(lds, nlds);
@@ -153,7 +190,9 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
     c.Lv = W.L + (size_t)slot * N.nzl; c.Uv = W.U + (size_t)slot * N.nzu; c.Dinv = W.Dinv + (size_t)slot * N.npad;
     c.rtol = W.rtol + (size_t)slot * N.npad; c.atol = W.atol + (size_t)slot * N.npad;
     ygood = W.ygood + (size_t)slot * N.npad;
+    if constexpr (ET) { c.Pb = W.Pb + (size_t)slot * N.npad; c.zb = W.zb + (size_t)slot * N.npad; }
   };
+  c.cell = nullptr; c.hcrec = nullptr; c.hc = A.hc_tab; c.Pb = nullptr; c.zb = nullptr; c.prm = &P;
   const int own_slot = A.slot0 + blockIdx.x;
   bind(own_slot);
   c.marker = own_slot == 0 ? W.marker : nullptr;
@@ -249,6 +288,17 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
       g_wc.Tgas = cp[RACGPU_P_TGAS]; g_wc.nsite = cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES];
       dev_mark(c, 1);
       { double rT, aT; dev_tolerances(N, P, A.tolj ? A.tolj[cell] : P.tol_j, cp[RACGPU_P_D2H], c.rtol, c.atol, rT, aT, lane); g_wc.rT = rT; g_wc.aT = aT; }
+      if constexpr (ET) { // set_initial_condition_4solver (src/disk.f90:2066-2073): y(NEQ) = Tgas; T evolves when the cell gains energy
+        c.cell = cp; c.hcrec = A.hc + (size_t)cell * kNHC;
+        const int j = A.tolj ? A.tolj[cell] : P.tol_j;
+        g_T.y = cp[RACGPU_P_TGAS]; g_T.savf = 0.0; g_T.acor = 0.0; g_T.ewt = 0.0; g_T.rtol = g_wc.rT; g_T.atol = g_wc.aT;
+        for (int k = 0; k < 6; ++k) g_T.yh[k] = 0.0;
+        for (int k = 0; k < 10; ++k) g_T.Pc[k] = 0.0;
+        g_T.Pd = 1.0; g_T.schur = 1.0; g_T.rh2 = 0.0;
+        g_T.t_scale_tol = j == 1 ? 1e-6 : j == 2 ? 1e-4 : j == 3 ? 1e-3 : j == 4 ? 1e-2 : 1e-1; // chem_set_solver_flags_alt (src/chemistry.f90:220-244)
+        g_T.evolT = c.hcrec[H_EN_GAIN_TOT] > 0.0 ? 1 : 0;
+        g_T.maySwitchT = ((const RG_GLOBAL DevHC *)A.hc_tab)->cfg.may_switch_T;
+      }
       dev_mark(c, 2);
       for (int i = lane; i < n; i += 64) c.y[i] = A.yio[(size_t)cell * n + i];
       wave_sync();
@@ -274,7 +324,7 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
     io.rec = pk; io.resume = RESUME; io.counters = W.counter; io.ncell = A.ncell; io.nwaves = (int)gridDim.x;
     io.park_max = (TEAM == 1 && pk) ? A.park_max : 0;
     io.ypark = ypark; io.cell = cell; io.slot = slot; io.cyc0 = cyc0; io.park_list = A.park_list; io.park_count = A.park_count;
-    CellResult R = dev_evol_solve(N, P, c, t0, t_max, dt_first, nrec, rec, tos, ygood, cell == 0 ? W.trace : nullptr, io);
+    CellResult R = dev_evol_solve<ET>(N, P, c, t0, t_max, dt_first, nrec, rec, tos, ygood, cell == 0 ? W.trace : nullptr, io);
     dev_mark(c, 4);
     wave_sync();
     // hand-off (src/disk.f90:1716-1733): record(:, isav), touts(isav); with isav <= 1 ("No useful data produced") the
@@ -296,6 +346,11 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
         double *o = A.cell_out + (size_t)cell * RACGPU_NOUT;
         if (useful) o[RACGPU_O_N_MOL_ON_GRAIN] = nmol;
         o[RACGPU_O_T_END] = R.t_final;
+        if constexpr (ET) { // c%par%Tgas = record(nS+1, isav) (src/disk.f90:1732); the coefficient of the last chem_cal_rates call
+          if (useful) o[RACGPU_O_TGAS] = R.T_good;
+          o[RACGPU_O_EVOLT_END] = (double)R.evolT_end;
+          if (N.r_h2form >= 0) o[RACGPU_O_R_H2_FORM] = g_T.rh2;
+        } else if (useful) o[RACGPU_O_TGAS] = cp[RACGPU_P_TGAS];
       }
       if (A.stats) {
         long long *s = A.stats + (size_t)cell * RACGPU_NSTAT;
@@ -333,6 +388,11 @@ __global__ __launch_bounds__(64) void k_solve(const DevNet *__restrict__ Np, con
 __global__ __launch_bounds__(64 * kTeam) void k_solve_team(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
   extern __shared__ double lds[];
   solve_body<kTeam, false>(*Np, *Pp, W, A, lds);
+}
+// gas temperature co-evolving with the chemistry (chemsol_params%evolT): one wave per cell
+__global__ __launch_bounds__(64) void k_solve_T(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
+  extern __shared__ double lds[];
+  solve_body<1, false, false, true>(*Np, *Pp, W, A, lds);
 }
 // columns of cells in dependency order, one team per column at a time (racgpu_column_sweep)
 __global__ __launch_bounds__(64 * kTeam) void k_solve_columns(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
@@ -426,6 +486,9 @@ struct racgpu_network {
   double *co_logNH2 = nullptr, *co_logNCO = nullptr, *co_lnf = nullptr; int co_nrow = 0, co_ncol = 0; // racgpu_set_co_shielding_table
   bool timed = false;
   int cu_count = 0;
+  // heating/cooling (evolT): host tables, their device copy, and the arrays it points at
+  HostHC hhc; HcConfig hcfg{}; DevHC *hc_dev = nullptr; std::vector<void *> hc_allocs;
+  void upload_hc();
 
   template <typename T>
   const T *up(const std::vector<T> &h) {
@@ -454,6 +517,8 @@ struct racgpu_network {
     if (team_stream) (void)hipStreamDestroy(team_stream);
     if (parked_host) (void)hipHostFree(parked_host);
     for (double *q : {co_logNH2, co_logNCO, co_lnf}) if (q) (void)hipFree(q);
+    for (void *q : hc_allocs) (void)hipFree(q);
+    if (hc_dev) (void)hipFree(hc_dev);
   }
 };
 
@@ -765,6 +830,30 @@ void racgpu_network::upload() {
   uploaded = true;
 }
 
+void racgpu_network::upload_hc() {
+  if (!hhc.loaded) throw std::runtime_error("gas-temperature evolution needs racgpu_heating_cooling_load first");
+  for (void *q : hc_allocs) (void)hipFree(q);
+  hc_allocs.clear();
+  auto H = std::make_unique<DevHC>();
+  std::memset(H.get(), 0, sizeof(DevHC));
+  H->cfg = hcfg; H->h2 = hhc.h2; H->h2o = hhc.h2o; H->co = hhc.co; H->nii = hhc.nii; H->siii = hhc.siii; H->feii = hhc.feii;
+  auto put = [&](const void *src, size_t bytes) { void *d = nullptr; HIP_OK(hipMalloc(&d, std::max<size_t>(bytes, 8))); if (bytes) HIP_OK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice)); hc_allocs.push_back(d); return d; };
+  const size_t nh = hhc.heat_rxn.size();
+  std::vector<uint16_t> ha(nh), hb(nh);
+  for (size_t i = 0; i < nh; ++i) { ha[i] = (uint16_t)(net.R[hhc.heat_rxn[i]].reac[0] - 1); hb[i] = (uint16_t)(net.R[hhc.heat_rxn[i]].reac[1] - 1); }
+  H->nheat = (int)nh;
+  H->heat_rxn = (const int *)put(hhc.heat_rxn.data(), nh * sizeof(int)); H->heat_val = (const double *)put(hhc.heat_val.data(), nh * sizeof(double));
+  H->heat_a = (const uint16_t *)put(ha.data(), nh * 2); H->heat_b = (const uint16_t *)put(hb.data(), nh * 2);
+  auto sp = [&](const char *nm) { return net.species_index(nm) - 1; };
+  H->i_H2 = sp("H2"); H->i_HI = sp("H"); H->i_E = sp("E-"); H->i_CI = sp("C"); H->i_CII = sp("C+"); H->i_OI = sp("O"); H->i_O2 = sp("O2"); H->i_CO = sp("CO");
+  H->i_H2O = sp("H2O"); H->i_OH = sp("OH"); H->i_Hplus = sp("H+"); H->i_Heplus = sp("He+"); H->i_gH = sp("gH"); H->i_NII = sp("N+"); H->i_SiII = sp("Si+");
+  H->i_FeII = sp("Fe+");
+  for (int k = 0; k < 10; ++k) { H->idx10[k] = net.idx10[k] - 1; H->kref_row[k] = net.ref_kref_Trow[k]; }
+  H->kref_col0 = net.ref_kref_Tcol0;
+  if (!hc_dev) HIP_OK(hipMalloc((void **)&hc_dev, sizeof(DevHC)));
+  HIP_OK(hipMemcpy(hc_dev, H.get(), sizeof(DevHC), hipMemcpyHostToDevice));
+}
+
 void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   if (slots <= ws_slots && rate_cells <= ws_rate_cells) return;
   slots = std::max(slots, ws_slots); rate_cells = std::max(rate_cells, ws_rate_cells);
@@ -781,6 +870,8 @@ void racgpu_network::ensure_workspace(long slots, long rate_cells) {
   ws.ygood = alloc((size_t)slots * dn.npad);
   ws.acor = alloc((size_t)slots * dn.npad);
   ws.ewt = alloc((size_t)slots * dn.npad);
+  ws.Pb = alloc((size_t)slots * dn.npad);
+  ws.zb = alloc((size_t)slots * dn.npad);
   ws.park = alloc((size_t)slots * (dn.npad + kParkWords));
   void *c = nullptr;
   HIP_OK(hipMalloc(&c, 64 + (size_t)slots * sizeof(int)));
@@ -1144,6 +1235,7 @@ double racgpu_last_kernel_ms(const racgpu_network *h) {
 struct PassBufs {
   const double *cells; double *y; const double *t0; const int *tolj; double *t_final; int *quality; long long *stats;
   double *record, *touts, *cell_out;
+  const double *hc = nullptr; // [ncell][RACGPU_NHC]: gas temperature co-evolving (k_solve_T) when given
 };
 static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const PassBufs &B, int flags, bool use_hints, bool first_timed) {
   const size_t nS = h->dn.nS;
@@ -1206,6 +1298,13 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
     if (const char *e = std::getenv("RACGPU_PARK_PER_CU")) park_per_cu = std::max(1, std::atoi(e)); // developer aid
     const int park_max = h->park_enabled ? h->cu_count * park_per_cu : 0;
     A.park_max = park_max; A.park_list = h->ws.counter + 16; A.park_count = h->ws.counter + 4;
+    if (B.hc) { // gas temperature co-evolving: one wave per cell throughout (no teams, no hand-over)
+      A.hc = B.hc + (size_t)c0 * kNHC; A.hc_tab = h->hc_dev; A.park_max = 0;
+      const long grid = std::max<long>(1, std::min<long>(slots, A.ncell));
+      hipLaunchKernelGGL(k_solve_T, dim3((unsigned)grid), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, A);
+      HIP_OK(hipGetLastError());
+      continue;
+    }
     // Cells that would take more than team_frac of the pass's ideal length on their own (sum of costs / wave slots) go to
     // k_solve_team, four waves each, on a second stream and ahead of the bulk kernel; they are the head of the sorted order.
     long nteamc = 0;
@@ -1247,20 +1346,40 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
   }
 }
 
+static void ensure_hc(racgpu_network *h) { if (!h->hc_dev) h->upload_hc(); }
+
 static void push_params(racgpu_network *h, const DevParams &P) {
   HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream)); // P lives on the caller's stack frame
 }
 
+static int evol_solve_batch_impl(racgpu_network *h, const racgpu_params *p, int64_t ncell, const double *cells, const double *hc, double *y, const double *t0,
+                                 const int32_t *tol_j, double *t_final, int32_t *quality, int64_t *stats, double *record, double *touts,
+                                 double *cell_out, int flags, int mem);
+
 int racgpu_evol_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell, const double *cells, double *y, const double *t0,
                             const int32_t *tol_j, double *t_final, int32_t *quality, int64_t *stats, double *record, double *touts,
                             double *cell_out, int flags, int mem) {
+  return evol_solve_batch_impl(h, p, ncell, cells, nullptr, y, t0, tol_j, t_final, quality, stats, record, touts, cell_out, flags, mem);
+}
+
+int racgpu_evolT_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t ncell, const double *cells, const double *hc, double *y, const double *t0,
+                             const int32_t *tol_j, double *t_final, int32_t *quality, int64_t *stats, double *record, double *touts,
+                             double *cell_out, int flags, int mem) {
+  if (!hc) return fail("hc must not be null (racgpu_evol_solve_batch is the fixed-T entry point)");
+  return evol_solve_batch_impl(h, p, ncell, cells, hc, y, t0, tol_j, t_final, quality, stats, record, touts, cell_out, flags, mem);
+}
+
+static int evol_solve_batch_impl(racgpu_network *h, const racgpu_params *p, int64_t ncell, const double *cells, const double *hc, double *y, const double *t0,
+                                 const int32_t *tol_j, double *t_final, int32_t *quality, int64_t *stats, double *record, double *touts,
+                                 double *cell_out, int flags, int mem) {
   if (!h) return fail("null network");
   if (ncell <= 0) return 0;
   if (ncell > 0x7fffffffLL) return fail("ncell exceeds 2^31-1");
   if (!cells || !y) return fail("cells and y must not be null");
   return guarded([&] {
     h->upload();
+    if (hc) ensure_hc(h);
     DevParams P = to_dev(p);
     push_params(h, P);
     const size_t nS = h->dn.nS;
@@ -1275,7 +1394,8 @@ int racgpu_evol_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t n
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, mem, true), dy(y, ncell * nS * 8, mem, true), dt0(t0, ncell * 8, mem, true),
         dj(tol_j, ncell * 4, mem, true), dt(t_final, ncell * 8, mem, false), dq(quality, ncell * 4, mem, false),
         ds(stats, ncell * RACGPU_NSTAT * 8, mem, false), drec(record, (size_t)ncell * P.n_record * (nS + 1) * 8, mem, false),
-        dto(touts, (size_t)ncell * P.n_record * 8, mem, false), dout(cell_out, (size_t)ncell * RACGPU_NOUT * 8, mem, true);
+        dto(touts, (size_t)ncell * P.n_record * 8, mem, false), dout(cell_out, (size_t)ncell * RACGPU_NOUT * 8, mem, true),
+        dhc(hc, (size_t)ncell * kNHC * 8, mem, true);
     int *marker_host = nullptr;
     h->ws.marker = nullptr;
     const char *dbgwait = std::getenv("RACGPU_DEBUG_WAIT");
@@ -1285,7 +1405,7 @@ int racgpu_evol_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t n
       HIP_OK(hipHostGetDevicePointer((void **)&h->ws.marker, marker_host, 0));
     }
     PassBufs B{(const double *)dc.d, (double *)dy.d, (const double *)dt0.d, (const int *)dj.d, (double *)dt.d, (int *)dq.d, (long long *)ds.d,
-               (double *)drec.d, (double *)dto.d, (double *)dout.d};
+               (double *)drec.d, (double *)dto.d, (double *)dout.d, (const double *)dhc.d};
     solve_pass(h, P, (long)ncell, B, flags, true, true);
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -1312,6 +1432,62 @@ int racgpu_evol_solve_batch(racgpu_network *h, const racgpu_params *p, int64_t n
         std::fprintf(stderr, "[racgpu trace] call %3d tn=%.6e h=%.6e hu=%.6e nq=%g kflag=%g nst=%g nfe=%g nje/nlu=%g\n", i, tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6], tr[7]);
       }
     }
+  });
+}
+
+void racgpu_hc_config_default(racgpu_hc_config *c) { // the reference's template (README.md:135-156)
+  std::memset(c, 0, sizeof *c);
+  c->heating_eff_chem = 0.3; c->heating_eff_H2form = 0.5; c->heating_eff_phd_H2 = 1.0; c->heating_eff_phd_H2O = 0.5; c->heating_eff_phd_OH = 0.5;
+  c->cooling_gg_coeff = 1.0; c->base_alpha = 0.01;
+  c->use_chemicalheatingcooling = 1; c->use_Xray_heating = 1; c->use_phdheating_H2 = 1; c->use_phdheating_H2OOH = 1; c->use_mygasgraincooling = 1;
+  c->may_switch_T = 1;
+}
+
+int racgpu_heating_cooling_load(racgpu_network *h, const racgpu_hc_config *cfg, const char *enthalpy_file, const char *neufeld_tables,
+                                const char *nii_lut, const char *siii_lut, const char *feii_lut) {
+  if (!h || !cfg || !enthalpy_file || !neufeld_tables || !nii_lut || !siii_lut || !feii_lut) return fail("null argument");
+  static_assert(sizeof(racgpu_hc_config) == sizeof(HcConfig), "racgpu_hc_config and HcConfig must have the same layout");
+  return guarded([&] {
+    h->hhc.loaded = false;
+    load_species_enthalpies(h->net, enthalpy_file, h->hhc);
+    load_neufeld_tables(neufeld_tables, h->hhc);
+    load_ion_lut(nii_lut, h->hhc.nii); load_ion_lut(siii_lut, h->hhc.siii); load_ion_lut(feii_lut, h->hhc.feii);
+    std::memcpy(&h->hcfg, cfg, sizeof(HcConfig));
+    h->hhc.loaded = true;
+    if (h->hc_dev) { (void)hipFree(h->hc_dev); h->hc_dev = nullptr; } // re-uploaded by the next compute call
+  });
+}
+
+int racgpu_heat_reactions(const racgpu_network *h, int32_t *n, int32_t *rxn, double *heat) {
+  if (!h) return fail("null network");
+  if (!h->hhc.loaded) return fail("racgpu_heating_cooling_load has not been called");
+  if (n) *n = (int32_t)h->hhc.heat_rxn.size();
+  for (size_t i = 0; i < h->hhc.heat_rxn.size(); ++i) { if (rxn) rxn[i] = h->hhc.heat_rxn[i] + 1; if (heat) heat[i] = h->hhc.heat_val[i]; }
+  return 0;
+}
+
+
+int racgpu_evolT_hooks(racgpu_network *h, const racgpu_params *p, const double *cells, const double *hc, int64_t ncell, const double *y,
+                       double *ydot, double *terms, double *tcol, double *trow) {
+  if (!h) return fail("null network");
+  if (!cells || !hc || !y || !ydot || !terms) return fail("cells, hc, y, ydot and terms must not be null");
+  if ((tcol == nullptr) != (trow == nullptr)) return fail("tcol and trow go together");
+  return guarded([&] {
+    h->upload();
+    ensure_hc(h);
+    DevParams P = to_dev(p);
+    push_params(h, P);
+    const size_t nS = h->dn.nS;
+    DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dh(hc, (size_t)ncell * kNHC * 8, RACGPU_MEM_HOST, true),
+        dy(y, ncell * (nS + 1) * 8, RACGPU_MEM_HOST, true), dd(ydot, ncell * (nS + 1) * 8, RACGPU_MEM_HOST, false),
+        dt(terms, (size_t)ncell * HC_NTERMS * 8, RACGPU_MEM_HOST, false), dtc(tcol, ncell * (nS + 1) * 8, RACGPU_MEM_HOST, false),
+        dtr(trow, (size_t)ncell * 10 * 8, RACGPU_MEM_HOST, false);
+    h->ensure_workspace((long)ncell, (long)ncell);
+    hipLaunchKernelGGL(k_evolT_hooks, dim3((unsigned)ncell), dim3(64), lds_bytes(h->dn), h->stream, h->dn_dev, h->dp_dev, h->ws, (const DevHC *)h->hc_dev,
+                       (const double *)dc.d, (const double *)dh.d, (const double *)dy.d, tcol ? 1 : 0, (double *)dd.d, (double *)dt.d, (double *)dtc.d, (double *)dtr.d);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(h->stream));
+    dd.copy_out(); dt.copy_out(); dtc.copy_out(); dtr.copy_out();
   });
 }
 

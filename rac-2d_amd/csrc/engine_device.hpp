@@ -120,9 +120,11 @@ RG_DEV double dev_branching(int itype, double A, double B, double C, double T0, 
 
 // rh2 (may be null): where the cell's R_H2_form_rate_coeff goes -- the coefficient, still per second, of the last H2-formation
 // reaction (itype 0, or 63 with gH first), which the reference stores as a side effect (:804, :891)
+// Tover (may be null): the gas temperature to use instead of the record's (evolT: chem_ode_f sets chem_params%Tgas = y(NEQ) before
+// it calls chem_cal_rates, reference src/disk.f90:4577-4580)
 RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restrict__ cell, double *__restrict__ rates, int lane,
-                      double *__restrict__ rh2 = nullptr) {
-  const double Tgas = cell[0], Tdust = cell[1], n_gas = cell[2], D2H = cell[6], sites = cell[7];
+                      double *rh2 = nullptr, const double *Tover = nullptr) {
+  const double Tgas = Tover ? *Tover : cell[0], Tdust = cell[1], n_gas = cell[2], D2H = cell[6], sites = cell[7];
   const double T300 = Tgas / 300.0;
   const double Tred = cst::kB_SI * Tgas / (cst::eCharge_SI * cst::eCharge_SI * cst::Coulomb_SI / (cell[3] * 1e-2));
   double JNegaPosi = 0.0, JChargeNeut = 0.0;

@@ -11,8 +11,16 @@
 // The T slot (NEQ = nS+1) is inert at fixed temperature: its ydot, Jacobian row and column are zero, so it is
 // carried as two scalars (value and weight) that only enter the "too much accuracy" norm and the divisor of
 // every RMS norm, exactly as in the reference.
+// Gas-temperature co-evolution (chemsol_params%evolT; template parameter ET, kernel k_solve_T): the T entry of every
+// NEQ-vector is a scalar in LDS (struct TSlot) that takes part in every vector operation; the rate coefficients are
+// recomputed at the iterate's T before every f(y) (chem_ode_f, reference src/disk.f90:4577-4580), dT/dt comes from
+// dev_heating_cooling (realtime_heating_cooling_rate, :4664-4741), the T row and T column of the Jacobian from finite
+// differences (chem_ode_jac, :4878-4899) and the Newton matrix is solved as a bordered system around the species block's
+// LU (the reference orders T into its minimum-degree ordering; without pivoting the two agree to rounding).  With ET = false
+// nothing of this is compiled: k_solve is the fixed-T kernel of rounds 1 and 2 to the last instruction.
 #pragma once
 #include "engine_device.hpp"
+#include "engine_hc.hpp"
 
 namespace racgpu {
 
@@ -27,6 +35,10 @@ struct CellCtx {
   int lane, n, npad;
   int nteam;      // waves working on this cell (1, or 4 in k_solve_team: wave 0 holds this context, the others serve it)
   int *marker;    // developer aid: host-visible progress word, or null
+  // ET only: the cell's record and heating/cooling record, the heating/cooling tables, and two more HBM vectors of the slot:
+  // the T column of P (rows = species) and (species block of P)^-1 times it
+  const double *cell, *hcrec; const DevHC *hc; double *Pb, *zb;
+  const DevParams *prm;
 };
 
 // Per-cell constants and the per-phase cycle counters live in LDS and are read where they are used: as kernel-long
@@ -42,6 +54,15 @@ struct WaveConst {
 };
 enum { CYC_RHS = 0, CYC_JAC, CYC_LU, CYC_SOLVE, CYC_LU_PART };
 static __shared__ volatile WaveConst g_wc;
+// ET: the T entry of the NEQ-vectors (iterate, f, accumulated correction, inverse weight, tolerances, Nordsieck columns), the
+// border of the Newton matrix (T row at the ten special species, T-T entry, Schur complement), R_H2_form_rate_coeff of the last
+// chem_cal_rates call, and the switches chemsol_params%evolT / %maySwitchT / %t_scale_tol
+struct TSlot {
+  double y, savf, acor, ewt, rtol, atol, yh[6];
+  double Pc[10], Pd, schur, rh2, t_scale_tol;
+  int evolT, maySwitchT;
+};
+static __shared__ volatile TSlot g_T;
 // wave 0's requests to the other waves of its team (k_solve_team): written before a barrier, read after it
 enum { T_EXIT = 0, T_LU = 1, T_JAC = 2 };
 struct TeamCtl { int cmd, fail, cell, slot; double con; }; // cell: wave 0's current cell (its rate vector); slot: its workspace slot; con: -h*el0 of the Jacobian request
@@ -54,6 +75,10 @@ RG_DEV void dev_mark(const CellCtx &c, int id) {
   if (c.marker && c.lane == 0) __hip_atomic_store(c.marker, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+constexpr double kUround = 2.220446049250313e-16; // DUMACH()
+constexpr double kCcmax = 0.3, kCcmxj = 0.2, kPsmall = 1000.0 * kUround, kRbig = 0.01 / kPsmall;
+constexpr int kMaxord = 5, kMaxcor = 3, kMsbp = 20, kMxncf = 10, kMsbj = 50;
+
 struct Lsodes { // the scalars ODEPACK keeps in COMMON /DLS001/ and /DLSS01/ plus the driver's SAVEd locals
   double conit, crate, hold, rmax, el0, h, hmxi, hu, rc, tn;
   double con0, conmin, tcrit, h0;
@@ -63,16 +88,13 @@ struct Lsodes { // the scalars ODEPACK keeps in COMMON /DLS001/ and /DLSS01/ plu
   int ncalls; double *trace; int trace_cap; // developer aid
 };
 
-constexpr double kUround = 2.220446049250313e-16; // DUMACH()
-constexpr double kCcmax = 0.3, kCcmxj = 0.2, kPsmall = 1000.0 * kUround, kRbig = 0.01 / kPsmall;
-constexpr int kMaxord = 5, kMaxcor = 3, kMsbp = 20, kMxncf = 10, kMsbj = 50;
-
-template <typename V>
-RG_DEV double dev_vnorm(const CellCtx &c, V v) { // DVNORM over NEQ = nS+1 entries, the T entry being zero
+template <bool ET = false, typename V>
+RG_DEV double dev_vnorm(const CellCtx &c, V v, double vT = 0.0) { // DVNORM over NEQ = nS+1 entries (fixed T: the T entry is zero)
   double s = 0.0;
   const rsrc_t bE = mkbuf(c.ewt);
   vec_trips<RG_VEC_TRIP, double>(c.n, c.npad, [&](int i0) { return bload_f64(bE, c.lane * 8, i0 * 8); },
                        [&](int i0, double e) { const int i = i0 + c.lane; if (i < c.n) { const double q = v(i) * e; s += q * q; } });
+  if constexpr (ET) { const double q = vT * g_T.ewt; return sqrt((wave_sum(s) + q * q) * g_wc.inv_neq); }
   return sqrt(wave_sum(s) * g_wc.inv_neq);
 }
 
@@ -106,6 +128,7 @@ struct D2 { double a, b; };
 struct D3 { double a, b, c; };
 struct DCols { double v[kMaxord + 2]; }; // the Nordsieck columns of one block (+ one more vector)
 
+template <bool ET = false>
 RG_DEV void dev_rescale(const CellCtx &c, Lsodes &s, double rh, bool apply_hmin) { // DSTODE labels 170/175
   if (apply_hmin) rh = fmax(rh, 0.0); // RH = MAX(RH, HMIN/ABS(H)) with HMIN = 0
   rh = fmin(rh, s.rmax);
@@ -117,11 +140,13 @@ RG_DEV void dev_rescale(const CellCtx &c, Lsodes &s, double rh, bool apply_hmin)
     r = r * rh;
     const int co = col_off(c, j - 1);
     vec_trips<RG_VEC_TRIP, double>(c.n, c.npad, [&](int i0) { return bload_f64(bY, l8, co + i0 * 8); }, [&](int i0, double v) { bstore_f64(bY, l8, co + i0 * 8, v * r); });
+    if constexpr (ET) g_T.yh[j - 1] = g_T.yh[j - 1] * r;
   }
   s.h = s.h * rh; s.rc = s.rc * rh; s.ialth = s.l;
 }
 
 // YH <- YH * Pascal (forward) or its inverse; DSTODE :865-874, :956-962
+template <bool ET = false>
 RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward, bool to_y = false) { // to_y: the new first column goes to y (LDS) as well
   const int nq = s.nq;
   const rsrc_t bY = mkbuf(c.yh);
@@ -146,9 +171,71 @@ RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward, bool to_
         if (j < nq) bstore_f64(bY, l8, col_off(c, j) + i0 * 8, d.v[j]);
       if (to_y && i0 + c.lane < c.n) c.y[i0 + c.lane] = d.v[0];
     });
+  if constexpr (ET) { // the same triangle on the T entries
+    double t[kMaxord + 1];
+    for (int j = 0; j <= kMaxord; ++j) t[j] = g_T.yh[j];
+    for (int jb = 1; jb <= nq; ++jb)
+      for (int j = nq - jb; j < nq; ++j) t[j] = forward ? t[j] + t[j + 1] : t[j] - t[j + 1];
+    for (int j = 0; j < nq; ++j) g_T.yh[j] = t[j];
+    if (to_y) g_T.y = t[0];
+  }
+}
+
+// f(y) into savf.  ET and the cell's T still evolving: chem_ode_f's three steps (reference src/disk.f90:4569-4659) -- rate
+// coefficients at the iterate's T, the species part, dT/dt.  The rate vector and R_H2_form_rate_coeff stay as this call leaves them.
+template <bool ET>
+RG_DEV void dev_f(const DevNet &N, const CellCtx &c, double *ydot, double *ydotT = nullptr, const double *Tat = nullptr) {
+  if constexpr (ET) {
+    if (g_T.evolT) {
+      double T = Tat ? *Tat : g_T.y;
+      dev_rates(N, *c.prm, c.cell, c.rates, c.lane, (double *)&g_T.rh2, &T);
+      dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, ydot, c.lane);
+      const double td = dev_heating_cooling(N, *(const RG_GLOBAL DevHC *)c.hc, c.cell, c.hcrec, c.y, T, c.rates, g_T.rh2, c.lane);
+      if (ydotT) *ydotT = td; else g_T.savf = td;
+      return;
+    }
+    if (ydotT) *ydotT = 0.0; else g_T.savf = 0.0;
+  }
+  dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, ydot, c.lane);
+}
+
+// chem_ode_jac's finite differences (reference src/disk.f90:4878-4899), taken after the species columns as DPRJS calls them (j = 1..NEQ),
+// scaled into the border of P = I + con J.  T row: d(dT/dt)/dy_j for the ten special species with y_j >= 0, step 1e-2 y_j + 1e-6 D2H; the
+// base value is the dT/dt of the f(y) that preceded this call (same y, same rates: g_T.savf).  T column: (f(y, T + dT) - f(y, T)) / dT with
+// dT = 1e-2 T + 1, f(y, T) being savf; the rate vector is left at T + dT, as in the reference.  wx (LDS) is used as scratch.
+RG_DEV void dev_T_border(const DevNet &N, const CellCtx &c, double con) {
+  const RG_GLOBAL DevHC &H = *(const RG_GLOBAL DevHC *)c.hc;
+  const double Tc = g_T.y, r1 = g_T.savf, d2h = c.cell[6];
+  for (int k = 0; k < 10; ++k) {
+    const int j = H.idx10[k];
+    double pc = 0.0;
+    if (j >= 0) {
+      const double yj = c.y[j];
+      if (yj >= 0.0) {
+        const double dy = yj * 1e-2 + d2h * 1e-6;
+        wave_sync();
+        if (c.lane == 0) c.y[j] = yj + dy;
+        wave_sync();
+        const double r2 = dev_heating_cooling(N, H, c.cell, c.hcrec, c.y, Tc, c.rates, g_T.rh2, c.lane);
+        wave_sync();
+        if (c.lane == 0) c.y[j] = yj;
+        wave_sync();
+        pc = (r2 - r1) / dy;
+      }
+    }
+    g_T.Pc[k] = pc * con;
+  }
+  const double dT = Tc * 1e-2 + 1.0, T2 = Tc + dT;
+  double td2;
+  dev_f<true>(N, c, c.wx, &td2, &T2);
+  const rsrc_t bB = mkbuf(c.Pb);
+  for (int i0 = 0; i0 < c.n; i0 += 64) { const int i = i0 + c.lane; if (i < c.n) bstore_f64(bB, c.lane * 8, i0 * 8, (c.wx[i] - c.savf[i]) / dT * con); }
+  g_T.Pd = (td2 - r1) / dT * con + 1.0;
+  wave_sync();
 }
 
 // DPRJS for MITER = 1.  y (LDS) holds the predicted values.
+template <bool ET = false>
 RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
   const double hl0 = s.h * s.el0, con = -hl0;
   bool jok = true;
@@ -183,6 +270,16 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
           if (in) bstore_f64(bP, l8, e0 * 8, pij);
         }
       }
+      if constexpr (ET) { // the border of P: T column (rows = species), T row, T-T entry
+        if (g_T.evolT) {
+          const rsrc_t bB = mkbuf(c.Pb);
+          vec_trips<RG_VEC_TRIP, double>(c.n, c.npad, [&](int i0) { return bload_f64(bB, l8, i0 * 8); }, [&](int i0, double v) { bstore_f64(bB, l8, i0 * 8, v * rcon); });
+          for (int k = 0; k < 10; ++k) g_T.Pc[k] = g_T.Pc[k] * rcon;
+          double pd = g_T.Pd - 1.0;
+          if (fabs(pd) < kPsmall) lost = true;
+          g_T.Pd = pd * rcon + 1.0;
+        }
+      }
       if (wave_any(lost)) { s.iplost = 1; s.conmin = fmin(fabs(s.con0), s.conmin); }
     }
   }
@@ -198,6 +295,7 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
       } else {
         dev_build_P<true>(N, c.rates, g_wc.nsite, c.y, con, true, c.Pv, c.lane);
       }
+      if constexpr (ET) { if (g_T.evolT) dev_T_border(N, c, con); }
       cyc_add(CYC_JAC, dev_clock() - t0);
     }
     dev_mark(c, 3001);
@@ -215,11 +313,52 @@ RG_DEV void dev_prjs(const DevNet &N, const CellCtx &c, Lsodes &s) {
     cyc_add(CYC_LU, dev_clock() - t0);
     for (int k = 0; k < 4; ++k) cyc_add(CYC_LU_PART + k, part[k]);
   }
+  if constexpr (ET) {
+    // the bordered system [A b; c^T d]: z = A^-1 b once per factorisation, Schur complement d - c.z.  f(y) is parked in the
+    // accumulated-correction vector (dead until the corrector zeroes it) while its LDS vector serves the solve.
+    if (g_T.evolT && s.ierpj == 0) {
+      const rsrc_t bA = mkbuf(c.acor), bB = mkbuf(c.Pb), bZ = mkbuf(c.zb);
+      const int l8 = c.lane * 8;
+      wave_sync();
+      for (int i0 = 0; i0 < c.n; i0 += 64) { const int i = i0 + c.lane; if (i < c.n) { bstore_f64(bA, l8, i0 * 8, c.savf[i]); c.savf[i] = bload_f64(bB, l8, i0 * 8); } }
+      wave_sync();
+      dev_solve(N, c.Lv, c.Uv, c.Dinv, c.savf, c.wx, c.lane);
+      const RG_GLOBAL DevHC &H = *(const RG_GLOBAL DevHC *)c.hc;
+      double dot = 0.0;
+      for (int k = 0; k < 10; ++k) { const int j = H.idx10[k]; if (j >= 0) dot = dot + g_T.Pc[k] * c.savf[j]; }
+      const double sc = g_T.Pd - dot;
+      g_T.schur = sc;
+      if (sc == 0.0) s.ierpj = 1;
+      wave_sync();
+      for (int i0 = 0; i0 < c.n; i0 += 64) { const int i = i0 + c.lane; if (i < c.n) { bstore_f64(bZ, l8, i0 * 8, c.savf[i]); c.savf[i] = bload_f64(bA, l8, i0 * 8); } }
+      wave_sync();
+    }
+  }
   s.ierpj = uniform_i(wave_any(s.ierpj != 0) ? 1 : 0);
+}
+
+// x <- P^-1 x for the full NEQ system: the species block's factors, then the border (ET: the T entry of x is g_T.y)
+template <bool ET>
+RG_DEV void dev_solve_neq(const DevNet &N, const CellCtx &c) {
+  dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, c.lane);
+  if constexpr (ET) {
+    if (g_T.evolT) {
+      const RG_GLOBAL DevHC &H = *(const RG_GLOBAL DevHC *)c.hc;
+      double dot = 0.0;
+      for (int k = 0; k < 10; ++k) { const int j = H.idx10[k]; if (j >= 0) dot = dot + g_T.Pc[k] * c.y[j]; }
+      const double xT = (g_T.y - dot) / g_T.schur;
+      const rsrc_t bZ = mkbuf(c.zb);
+      wave_sync();
+      for (int i0 = 0; i0 < c.n; i0 += 64) { const int i = i0 + c.lane; if (i < c.n) c.y[i] = c.y[i] - bload_f64(bZ, c.lane * 8, i0 * 8) * xT; }
+      g_T.y = xT;
+      wave_sync();
+    }
+  }
 }
 
 // One step.  Returns kflag (0, -1, -2).  Structure follows the restatement validated on the CPU side; every
 // expression keeps the reference's operand order.
+template <bool ET = false>
 RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s) {
   const int n = c.n, lane = c.lane, l8 = c.lane * 8;
   const rsrc_t bY = mkbuf(c.yh), bA = mkbuf(c.acor), bE = mkbuf(c.ewt);
@@ -234,7 +373,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     dev_set_order(P, s);
   } else if (s.jstart < 0) {
     if (s.jstart == -1) { s.ipup = 1; s.lmax = kMaxord + 1; if (s.ialth == 1) s.ialth = 2; }
-    if (s.h != s.hold) { rh = s.h / s.hold; s.h = s.hold; iredo = 3; dev_rescale(c, s, rh, false); }
+    if (s.h != s.hold) { rh = s.h / s.hold; s.h = s.hold; iredo = 3; dev_rescale<ET>(c, s, rh, false); }
   }
 
   for (int guard = 0; guard < 64; ++guard) { // label 200; at most 10 + 10 + a few retries are possible
@@ -242,34 +381,37 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
     if (s.nst >= s.nslp + kMsbp) s.ipup = 1;
     s.tn = s.tn + s.h;
     dev_mark(c, 2000 + guard);
-    dev_pascal(c, s, true, true); // (the prediction is the corrector's first iterate: one pass over the array instead of two)
+    dev_pascal<ET>(c, s, true, true); // (the prediction is the corrector's first iterate: one pass over the array instead of two)
     dev_mark(c, 2100 + guard);
 
     bool converged = false;
     for (int pass = 0; pass < 4; ++pass) { // label 220: re-entered after a P refresh (at most twice: rescaled P, then fresh J)
       m = 0;
-      if (pass > 0) vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
+      if (pass > 0) { vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; }); if constexpr (ET) g_T.y = g_T.yh[0]; }
       else wave_sync();
-      { const long long t0 = dev_clock(); dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
+      { const long long t0 = dev_clock(); dev_f<ET>(N, c, c.savf); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
       dev_mark(c, 2200 + pass);
       if (s.ipup > 0) {
-        dev_prjs(N, c, s);
+        dev_prjs<ET>(N, c, s);
         dev_mark(c, 2300 + pass);
         s.ipup = 0; s.rc = 1.0; s.nslp = s.nst; s.crate = 0.7;
         if (s.ierpj != 0) break;
       }
       for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bA, l8, i0 * 8, 0.0);
+      if constexpr (ET) g_T.acor = 0.0;
       bool fail410 = false;
       for (;;) {
         vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                          [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) c.y[i] = s.h * c.savf[i] - (v.a + v.b); });
+        if constexpr (ET) g_T.y = s.h * g_T.savf - (g_T.yh[1] + g_T.acor);
         dev_mark(c, 2400 + m);
-        { const long long t0 = dev_clock(); dev_solve(N, c.Lv, c.Uv, c.Dinv, c.y, c.wx, lane); cyc_add(CYC_SOLVE, dev_clock() - t0); }
+        { const long long t0 = dev_clock(); dev_solve_neq<ET>(N, c); cyc_add(CYC_SOLVE, dev_clock() - t0); }
         dev_mark(c, 2500 + m);
-        del = dev_vnorm(c, [&](int i) { return c.y[i]; });
+        del = dev_vnorm<ET>(c, [&](int i) { return c.y[i]; }, ET ? (double)g_T.y : 0.0);
         const double el1 = P.elco[s.nq][1];
         vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                          [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) { const double a = v.b + c.y[i]; bstore_f64(bA, l8, i0 * 8, a); c.y[i] = v.a + el1 * a; } });
+        if constexpr (ET) { const double a = g_T.acor + g_T.y; g_T.acor = a; g_T.y = g_T.yh[0] + el1 * a; }
         if (m != 0) s.crate = fmax(0.2 * s.crate, del / delp);
         const double dcon = del * fmin(1.0, 1.5 * s.crate) / (P.tesco[s.nq][2] * s.conit);
         if (dcon <= 1.0) { converged = true; break; }
@@ -277,7 +419,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (m == kMaxcor) { fail410 = true; break; }
         if (m >= 2 && del > 2.0 * delp) { fail410 = true; break; }
         delp = del;
-        { const long long t0 = dev_clock(); dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
+        { const long long t0 = dev_clock(); dev_f<ET>(N, c, c.savf); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
       }
       if (converged) break;
       if (fail410 && s.jcur != 1) { s.icf = 1; s.ipup = 1; continue; }
@@ -286,10 +428,10 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
 
     if (!converged) { // label 430
       s.icf = 2; ncf++; s.rmax = 2.0; s.tn = told; s.nfail++;
-      dev_pascal(c, s, false);
+      dev_pascal<ET>(c, s, false);
       if (fabs(s.h) <= 0.0 || ncf == kMxncf) { s.kflag = -2; break; }
       rh = 0.25; s.ipup = 1; iredo = 1;
-      dev_rescale(c, s, rh, true);
+      dev_rescale<ET>(c, s, rh, true);
       continue;
     }
 
@@ -300,14 +442,16 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       double q = 0.0;
       vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bA, l8, i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
                        [&](int i0, D2 v) { const double w = v.a * v.b; if (i0 + lane < n) q += w * w; });
-      dsm = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][2];
+      double qT = 0.0;
+      if constexpr (ET) { const double w = g_T.acor * g_T.ewt; qT = w * w; }
+      dsm = sqrt((ET ? wave_sum(q) + qT : wave_sum(q)) * g_wc.inv_neq) / P.tesco[s.nq][2];
     }
 
     bool consider = false;
     double rhup = 0.0;
     if (dsm > 1.0) { // label 500
       s.kflag = s.kflag - 1; s.tn = told; s.nfail++;
-      dev_pascal(c, s, false);
+      dev_pascal<ET>(c, s, false);
       s.rmax = 2.0;
       if (fabs(s.h) <= 0.0) { s.kflag = -1; break; }
       if (s.kflag <= -3) { // label 640
@@ -315,8 +459,10 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         rh = 0.1;
         s.h = s.h * rh;
         vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; });
-        dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe++;
+        if constexpr (ET) g_T.y = g_T.yh[0];
+        dev_f<ET>(N, c, c.savf); s.nfe++;
         for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, 1) + i0 * 8, s.h * c.savf[i]); }
+        if constexpr (ET) g_T.yh[1] = s.h * g_T.savf;
         s.ipup = 1; s.ialth = 5;
         if (s.nq != 1) { s.nq = 1; s.l = 2; dev_set_order(P, s); }
         continue;
@@ -342,6 +488,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
             for (int j = 0; j <= kMaxord; ++j)
               if (j < l) bstore_f64(bY, l8, col_off(c, j) + i0 * 8, d.v[j] + el[j] * d.v[kMaxord + 1]);
           });
+        if constexpr (ET) for (int j = 0; j < l; ++j) g_T.yh[j] = g_T.yh[j] + P.elco[s.nq][j + 1] * g_T.acor;
       }
       s.ialth--;
       if (s.ialth == 0) { // label 520
@@ -349,7 +496,8 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (s.l != s.lmax) {
           vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                            [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) c.savf[i] = v.b - v.a; });
-          const double dup = dev_vnorm(c, [&](int i) { return c.savf[i]; }) / P.tesco[s.nq][3];
+          if constexpr (ET) g_T.savf = g_T.acor - g_T.yh[s.lmax - 1];
+          const double dup = dev_vnorm<ET>(c, [&](int i) { return c.savf[i]; }, ET ? (double)g_T.savf : 0.0) / P.tesco[s.nq][3];
           const double exup = 1.0 / (s.l + 1);
           rhup = 1.0 / (1.4 * pow(dup, exup) + 0.0000014);
         }
@@ -357,6 +505,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       } else {
         if (s.ialth <= 1 && s.l != s.lmax) {
           for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bY, l8, col_off(c, s.lmax - 1) + i0 * 8, bload_f64(bA, l8, i0 * 8));
+          if constexpr (ET) g_T.yh[s.lmax - 1] = g_T.acor;
         }
         goto done700;
       }
@@ -370,7 +519,9 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         double q = 0.0;
         vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, s.l - 1) + i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
                          [&](int i0, D2 v) { const double w = v.a * v.b; if (i0 + lane < n) q += w * w; });
-        const double ddn = sqrt(wave_sum(q) * g_wc.inv_neq) / P.tesco[s.nq][1];
+        double qT = 0.0;
+        if constexpr (ET) { const double w = g_T.yh[s.l - 1] * g_T.ewt; qT = w * w; }
+        const double ddn = sqrt((ET ? wave_sum(q) + qT : wave_sum(q)) * g_wc.inv_neq) / P.tesco[s.nq][1];
         const double exdn = 1.0 / s.nq;
         rhdn = 1.0 / (1.3 * pow(ddn, exdn) + 0.0000013);
       }
@@ -382,6 +533,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (rh < 1.1) { s.ialth = 3; goto done700; }
         const double r = P.elco[s.nq][s.l] / s.l;
         for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bY, l8, col_off(c, newq) + i0 * 8, bload_f64(bA, l8, i0 * 8) * r);
+        if constexpr (ET) g_T.yh[newq] = g_T.acor * r;
       } else {
         if (sel == 0) { newq = s.nq; rh = rhsm; }
         else { newq = s.nq - 1; rh = rhdn; if (s.kflag < 0 && rh > 1.0) rh = 1.0; }
@@ -389,7 +541,7 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         if (s.kflag <= -2) rh = fmin(rh, 0.2);
       }
       if (newq != s.nq) { s.nq = newq; s.l = s.nq + 1; dev_set_order(P, s); }
-      dev_rescale(c, s, rh, true);
+      dev_rescale<ET>(c, s, rh, true);
       if (iredo == 0) { s.rmax = 10.0; goto done700; }
       continue;
     }
@@ -401,11 +553,13 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
 done700: {
     const double r = 1.0 / P.tesco[s.nqu][2];
     vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bA, l8, i0 * 8); }, [&](int i0, double v) { bstore_f64(bA, l8, i0 * 8, v * r); });
+    if constexpr (ET) g_T.acor = g_T.acor * r;
   }
   s.hold = s.h; s.jstart = 1;
   return s.kflag;
 }
 
+template <bool ET = false>
 RG_DEV void dev_intdy0(const CellCtx &c, const Lsodes &s, double t) { // y <- interpolant at t
   const double sf = (t - s.tn) / s.h;
   const rsrc_t bY = mkbuf(c.yh);
@@ -424,8 +578,14 @@ RG_DEV void dev_intdy0(const CellCtx &c, const Lsodes &s, double t) { // y <- in
       for (int j = kMaxord; j >= 0; --j) d = (j <= nq) ? ((j == nq) ? v.v[j] : v.v[j] + sf * d) : d;
       if (i0 + c.lane < c.n) c.y[i0 + c.lane] = d;
     });
+  if constexpr (ET) {
+    double d = g_T.yh[nq];
+    for (int j = nq - 1; j >= 0; --j) d = g_T.yh[j] + sf * d;
+    g_T.y = d;
+  }
 }
 
+template <bool ET = false>
 RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some weight is <= 0
   // (folding the driver's TOLSF sum, which reads the same two vectors next, into this pass costs two registers kernel-wide and
   // with them the third wave per SIMD: tried, not kept)
@@ -438,14 +598,22 @@ RG_DEV bool dev_ewset(const CellCtx &c) { // DEWSET + inversion; false if some w
                      if (i0 + c.lane < c.n && e <= 0.0) bad = true;
                      bstore_f64(bE, l8, i0 * 8, 1.0 / e);
                    });
-  const double Tg = g_wc.Tgas, eT = g_wc.rT * fabs(Tg) + g_wc.aT;
-  if (eT <= 0.0) bad = true;
+  if constexpr (ET) {
+    const double eT = g_T.rtol * fabs(g_T.yh[0]) + g_T.atol;
+    if (eT <= 0.0) bad = true;
+    g_T.ewt = 1.0 / eT;
+  } else {
+    const double Tg = g_wc.Tgas, eT = g_wc.rT * fabs(Tg) + g_wc.aT;
+    if (eT <= 0.0) bad = true;
+  }
   return !wave_any(bad);
 }
 
+template <bool ET = false>
 RG_DEV void dev_finish(const CellCtx &c, const Lsodes &s, double &t) { // label 580 / 400
   const rsrc_t bY = mkbuf(c.yh);
   vec_trips<RG_VEC_TRIP, double>(c.n, c.npad, [&](int i0) { return bload_f64(bY, c.lane * 8, i0 * 8); }, [&](int i0, double v) { if (i0 + c.lane < c.n) c.y[i0 + c.lane] = v; });
+  if constexpr (ET) g_T.y = g_T.yh[0];
   t = s.tn;
 }
 
@@ -490,6 +658,7 @@ RG_DEV bool dev_should_park(const ParkIO &io, int lane) {
   return uniform_i(go) != 0;
 }
 
+template <bool ET = false>
 RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &c, Lsodes &s, double &t, double tout, int &istate, const ParkIO &io) {
   const double u = kUround;
   const int n = c.n, lane = c.lane, l8 = c.lane * 8;
@@ -512,6 +681,15 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
         const rsrc_t bP = mkbuf(c.Pv), bK = mkbuf(N.Pkref);
         for (int e0 = 0; e0 < N.nnzJ; e0 += 64)
           if (e0 + lane < N.nnzJ && (int)bload_u16(bK, lane * 2, e0 * 2) >= thresh) bstore_f64(bP, l8, e0 * 8, 0.0);
+        if constexpr (ET) { // the T row and the T column of the saved P lie in the same storage (the T column is its very end)
+          if (g_T.evolT) {
+            const RG_GLOBAL DevHC &H = *(const RG_GLOBAL DevHC *)c.hc;
+            for (int k = 0; k < 10; ++k) if (H.kref_row[k] >= thresh) g_T.Pc[k] = 0.0;
+            const rsrc_t bB = mkbuf(c.Pb);
+            for (int i0 = 0; i0 < n; i0 += 64) if (i0 + lane < n && H.kref_col0 + i0 + lane >= thresh) bstore_f64(bB, l8, i0 * 8, 0.0);
+            if (H.kref_col0 + n >= thresh) g_T.Pd = 0.0;
+          }
+        }
       }
     }
   }
@@ -519,9 +697,11 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
     s.h0 = 0.0;
     s.tn = t; s.nst = 0; s.h = 1.0;
     for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, i0 * 8, c.y[i]); }
-    dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, c.savf, lane); s.nfe = 1;
+    if constexpr (ET) g_T.yh[0] = g_T.y;
+    dev_f<ET>(N, c, c.savf); s.nfe = 1;
     for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; if (i < n) bstore_f64(bY, l8, col_off(c, 1) + i0 * 8, c.savf[i]); }
-    if (!dev_ewset(c)) { istate = -3; return; }
+    if constexpr (ET) g_T.yh[1] = g_T.savf;
+    if (!dev_ewset<ET>(c)) { istate = -3; return; }
     { const rsrc_t bP = mkbuf(c.Pv); for (int e0 = 0; e0 < N.nnzJ; e0 += 64) if (e0 + lane < N.nnzJ) bstore_f64(bP, l8, e0 * 8, 0.0); }
     if ((s.tcrit - tout) * (tout - t) < 0.0) { istate = -3; return; }
     s.jstart = 0; s.nslj = 0; s.nje = 0; s.nlu = 0; s.nslast = 0; s.hu = 0.0; s.nqu = 0;
@@ -533,7 +713,7 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
       for (int i0 = 0; i0 < n; i0 += 64) { const double r = bload_f64(bR, l8, i0 * 8); if (i0 + lane < n) tol = fmax(tol, r); }
 #pragma unroll
       for (int mm = 32; mm >= 1; mm >>= 1) tol = fmax(tol, __shfl_xor(tol, mm, 64));
-      tol = uniform_d(fmax(tol, g_wc.rT));
+      tol = uniform_d(fmax(tol, ET ? (double)g_T.rtol : (double)g_wc.rT));
       if (tol <= 0.0) {
         double tl = 0.0;
         for (int i0 = 0; i0 < n; i0 += 64) {
@@ -544,10 +724,11 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
 #pragma unroll
         for (int mm = 32; mm >= 1; mm >>= 1) tl = fmax(tl, __shfl_xor(tl, mm, 64));
         tol = uniform_d(tl);
-        { const double Tg = g_wc.Tgas; if (Tg != 0.0) tol = fmax(tol, g_wc.aT / fabs(Tg)); }
+        if constexpr (ET) { const double Tg = g_T.y; if (Tg != 0.0) tol = fmax(tol, g_T.atol / fabs(Tg)); }
+        else { const double Tg = g_wc.Tgas; if (Tg != 0.0) tol = fmax(tol, g_wc.aT / fabs(Tg)); }
       }
       tol = fmax(tol, 100.0 * u); tol = fmin(tol, 0.001);
-      double sum = dev_vnorm(c, [&](int i) { return c.savf[i]; });
+      double sum = dev_vnorm<ET>(c, [&](int i) { return c.savf[i]; }, ET ? (double)g_T.savf : 0.0);
       sum = 1.0 / (tol * w0 * w0) + tol * sum * sum;
       s.h0 = 1.0 / sqrt(sum);
       s.h0 = fmin(s.h0, tdist);
@@ -557,13 +738,14 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
     if (rh > 1.0) s.h0 = s.h0 / rh;
     s.h = s.h0;
     for (int i0 = 0; i0 < n; i0 += 64) bstore_f64(bY, l8, col_off(c, 1) + i0 * 8, s.h0 * bload_f64(bY, l8, col_off(c, 1) + i0 * 8));
+    if constexpr (ET) g_T.yh[1] = s.h0 * g_T.yh[1];
   } else { // Block D
     s.nslast = s.nst;
     if ((s.tn - s.tcrit) * s.h > 0.0) { istate = -3; return; }
     if ((s.tcrit - tout) * s.h < 0.0) { istate = -3; return; }
-    if ((s.tn - tout) * s.h >= 0.0) { dev_intdy0(c, s, tout); t = tout; istate = 2; return; }
+    if ((s.tn - tout) * s.h >= 0.0) { dev_intdy0<ET>(c, s, tout); t = tout; istate = 2; return; }
     const double hmx = fabs(s.tn) + fabs(s.h);
-    if (fabs(s.tn - s.tcrit) <= 100.0 * u * hmx) { dev_finish(c, s, t); t = s.tcrit; istate = 2; return; }
+    if (fabs(s.tn - s.tcrit) <= 100.0 * u * hmx) { dev_finish<ET>(c, s, t); t = s.tcrit; istate = 2; return; }
     const double tnext = s.tn + s.h * (1.0 + 4.0 * u);
     if ((tnext - s.tcrit) * s.h > 0.0) {
       s.h = (s.tcrit - s.tn) * (1.0 - 4.0 * u);
@@ -574,30 +756,32 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
   bool first = !reentry && (istate == 1);
   for (;;) { // Block E
     if (!first) {
-      if (s.nst - s.nslast >= s.mxstep) { istate = -1; dev_finish(c, s, t); return; }
-      if (!dev_ewset(c)) { istate = -6; dev_finish(c, s, t); return; }
+      if (s.nst - s.nslast >= s.mxstep) { istate = -1; dev_finish<ET>(c, s, t); return; }
+      if (!dev_ewset<ET>(c)) { istate = -6; dev_finish<ET>(c, s, t); return; }
     }
     first = false;
     {
       double q = 0.0;
       vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bE, l8, i0 * 8)}; },
                        [&](int i0, D2 w) { const double v = w.a * w.b; if (i0 + lane < n) q += v * v; });
-      const double Tg = g_wc.Tgas, vT = Tg / (g_wc.rT * fabs(Tg) + g_wc.aT);
+      double vT;
+      if constexpr (ET) vT = g_T.yh[0] * g_T.ewt;
+      else { const double Tg = g_wc.Tgas; vT = Tg / (g_wc.rT * fabs(Tg) + g_wc.aT); }
       const double tolsf = u * sqrt((wave_sum(q) + vT * vT) * g_wc.inv_neq);
       if (tolsf > 1.0) {
         if (s.nst == 0) { istate = -3; return; }
-        istate = -2; dev_finish(c, s, t); return;
+        istate = -2; dev_finish<ET>(c, s, t); return;
       }
     }
     dev_mark(c, 100000 + s.nst);
-    const int kflag = dev_stode(N, P, c, s);
+    const int kflag = dev_stode<ET>(N, P, c, s);
     dev_mark(c, 200000 + s.nst);
     if (s.trace_cap > 0) {
       if (s.trace && s.ncalls < s.trace_cap && lane == 0) {
         double *tr = s.trace + (size_t)s.ncalls * 8;
         tr[0] = s.tn; tr[1] = s.h; tr[2] = s.hu; tr[3] = s.nq; tr[4] = kflag; tr[5] = s.nst; tr[6] = s.nfe; tr[7] = s.nje * 10000.0 + s.nlu;
       }
-      if (++s.ncalls >= s.trace_cap) { istate = -3; dev_finish(c, s, t); return; }
+      if (++s.ncalls >= s.trace_cap) { istate = -3; dev_finish<ET>(c, s, t); return; }
     }
     if (kflag != 0) {
       istate = (kflag == -1) ? -4 : -5;
@@ -616,13 +800,17 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
         const double ob = __shfl_xor(big, mm, 64); const int oi = __shfl_xor(idx, mm, 64);
         if (ob > big || (ob == big && oi < idx)) { big = ob; idx = oi; }
       }
+      if constexpr (ET) { // the T entry is the last of the NEQ: it is the first index of the maximum only if strictly larger
+        const double szT = fabs(g_T.acor * g_T.ewt);
+        if (szT > big) { big = szT; idx = n; }
+      }
       s.imxer = uniform_i(big > 0.0 ? idx : 0);
-      dev_finish(c, s, t); return;
+      dev_finish<ET>(c, s, t); return;
     }
     s.init = 1;
-    if ((s.tn - tout) * s.h >= 0.0) { dev_intdy0(c, s, tout); t = tout; istate = 2; return; }
+    if ((s.tn - tout) * s.h >= 0.0) { dev_intdy0<ET>(c, s, tout); t = tout; istate = 2; return; }
     const double hmx = fabs(s.tn) + fabs(s.h);
-    if (fabs(s.tn - s.tcrit) <= 100.0 * u * hmx) { dev_finish(c, s, t); t = s.tcrit; istate = 2; return; }
+    if (fabs(s.tn - s.tcrit) <= 100.0 * u * hmx) { dev_finish<ET>(c, s, t); t = s.tcrit; istate = 2; return; }
     const double tnext = s.tn + s.h * (1.0 + 4.0 * u);
     if ((tnext - s.tcrit) * s.h > 0.0) { s.h = (s.tcrit - s.tn) * (1.0 - 4.0 * u); s.jstart = -2; }
     if (io.park_max > 0 && dev_should_park(io, lane)) { istate = kIstateParked; return; } // between two steps: hand the cell over to a team?
@@ -632,9 +820,14 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
 // chem_evol_solve for one cell.  y (LDS) in: abundances at t0; out: abundances at the end of the run.
 // ygood (HBM): the hand-off record, i.e. record(:, isav) of the caller's loop in calc_this_cell (reference
 // src/disk.f90:1716-1733): the last record whose T and H2 entries are not NaN.
-struct CellResult { double t_final, t_good; int quality, nerr, nrec_real, isav; long long nst, nfe, nje, nlu, qsum, errc; int nfail; bool parked; };
+struct CellResult { double t_final, t_good; int quality, nerr, nrec_real, isav; long long nst, nfe, nje, nlu, qsum, errc; int nfail; bool parked;
+                    double T_good; int evolT_end; }; // ET: T of the hand-off record; whether T was still evolving at the end
+// ET: the last records' T and times for the T-freeze test of chem_evol_solve (reference src/chemistry.f90:532-546), T of the hand-off record
+struct THist { double T[8], t[8], T_good; };
+static __shared__ volatile THist g_Th;
 
 
+template <bool ET = false>
 RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const CellCtx &c, double t0, double t_max, double dt_first,
                                  int n_record, double *__restrict__ record, double *__restrict__ touts, double *__restrict__ ygood,
                                  double *trace, const ParkIO &io) {
@@ -655,7 +848,8 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     // ~1.0 ms per factorisation).
     e.rt_total = 0.0; e.rt_last = 1e300;
     if (touts) { if (lane == 0) touts[0] = t0; }
-    if (record) { for (int i = lane; i < n; i += 64) record[i] = c.y[i]; if (lane == 0) record[n] = g_wc.Tgas; }
+    if (record) { for (int i = lane; i < n; i += 64) record[i] = c.y[i]; if (lane == 0) record[n] = ET ? (double)g_T.y : (double)g_wc.Tgas; }
+    if constexpr (ET) { g_Th.T[1] = g_T.y; g_Th.t[1] = t0; g_Th.T_good = g_T.y; }
   } else {
     s = io.rec->s;
     s.trace = nullptr;
@@ -677,7 +871,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
       istate = kIstateResume;
     }
     double t = e.t;
-    dev_lsodes_call(N, P, c, s, t, tout, istate, io);
+    dev_lsodes_call<ET>(N, P, c, s, t, tout, istate, io);
     if (istate == kIstateParked) { park0[0] = nst0; park0[1] = nfe0; park0[2] = nje0; park0[3] = nlu0; parked = true; break; }
     e.t = t;
     e.nst_acc = e.nst_acc + (s.nst - nst0); e.nfe_acc = e.nfe_acc + (s.nfe - nfe0); e.nje_acc = e.nje_acc + (s.nje - nje0); e.nlu_acc = e.nlu_acc + (s.nlu - nlu0);
@@ -685,12 +879,15 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     e.rt_total = e.rt_total + rt_this;
     wave_sync();
     if (touts) { if (lane == 0) touts[i - 1] = t; }
-    if (record) { double *rec = record + (size_t)(i - 1) * neq; for (int k = lane; k < n; k += 64) rec[k] = c.y[k]; if (lane == 0) rec[n] = g_wc.Tgas; }
+    if (record) { double *rec = record + (size_t)(i - 1) * neq; for (int k = lane; k < n; k += 64) rec[k] = c.y[k]; if (lane == 0) rec[n] = ET ? (double)g_T.y : (double)g_wc.Tgas; }
     e.nrr = i;
+    if constexpr (ET) { g_Th.T[i & 7] = g_T.y; g_Th.t[i & 7] = t; }
     {
       // the record calc_this_cell would hand back if the run ended here (src/disk.f90:1716-1721)
       const double yh2 = N.i_H2 >= 0 ? c.y[N.i_H2] : 0.0;
-      if (!(isnan(yh2) || isnan(g_wc.Tgas))) {
+      const double Tnow = ET ? (double)g_T.y : (double)g_wc.Tgas;
+      if (!(isnan(yh2) || isnan(Tnow))) {
+        if constexpr (ET) g_Th.T_good = Tnow;
         e.isav = i; e.t_good = t;
         const rsrc_t bG = mkbuf(ygood);
         for (int i0 = 0; i0 < n; i0 += 64) { const int k = i0 + lane; if (k < n) bstore_f64(bG, lane * 8, i0 * 8, c.y[k]); }
@@ -709,20 +906,31 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
       e.errc = e.errc + (1ll << (istate == -1 ? 0 : istate == -4 ? 16 : istate == -5 ? 32 : 48));
       if (istate == -4 || istate == -5) { // loosen the offending component's tolerances
         const int idx = s.imxer;
-        if (lane == 0) { c.rtol[idx] = fmin(c.rtol[idx] * 10.0, 1e-3); c.atol[idx] = fmin(c.atol[idx] * 100.0, 1e-20); }
+        if (ET && idx >= n) { g_T.rtol = fmin(g_T.rtol * 10.0, 1e-2); g_T.atol = fmin(g_T.atol * 100.0, 1.0); } // the T slot has caps of its own (src/chemistry.f90:334-337)
+        else if (lane == 0) { c.rtol[idx] = fmin(c.rtol[idx] * 10.0, 1e-3); c.atol[idx] = fmin(c.atol[idx] * 100.0, 1e-20); }
         wave_sync();
       }
       if (istate == -3) { e.qual = e.qual + 256; break; }
       if (e.nerr_c < 3) istate = 3; else { istate = 1; e.nerr_c = 0; }
     }
     {
-      bool bad = !(g_wc.Tgas > 0.0);
+      bool bad = ET ? !(g_T.y > 0.0) : !(g_wc.Tgas > 0.0);
       if (N.i_gH2 >= 0 && fabs(c.y[N.i_gH2]) > 1.0) bad = true;
       if (N.i_gH2O >= 0 && fabs(c.y[N.i_gH2O]) > 1.0) bad = true;
       if (N.i_gH >= 0 && fabs(c.y[N.i_gH]) > 1.0) bad = true;
       if (N.i_H >= 0 && fabs(c.y[N.i_H]) > 2.0) bad = true;
       if (N.i_E >= 0 && fabs(c.y[N.i_E]) > 1.0) bad = true;
       if (wave_any(bad)) { e.qual = e.qual + 512; break; }
+    }
+    if constexpr (ET) {
+      // the T-freeze test (src/chemistry.f90:532-546): once T has moved by less than t_scale_tol (T1 + T2) dt / t_max over the last
+      // five records, the solver restarts with T held fixed -- and the rate coefficients as the last chem_cal_rates call left them
+      if (g_T.maySwitchT && g_T.evolT && i > 10 && t > 1e-2 * s.tcrit) {
+        double T1 = g_Th.T[i & 7], T2 = T1;
+        for (int k = 1; k < 5; ++k) { const double v = g_Th.T[(i - k) & 7]; T1 = fmax(T1, v); T2 = fmin(T2, v); }
+        const double dtt = g_Th.t[i & 7] - g_Th.t[(i - 5) & 7];
+        if ((T1 - T2) < g_T.t_scale_tol * (T1 + T2) * dtt / s.tcrit) { istate = 1; g_T.evolT = 0; }
+      }
     }
     if (P.steps_reset > 0 && i % P.steps_reset == 0) istate = 1;
     e.istate = istate;
@@ -758,7 +966,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
     for (int i = nrr + 1; i <= n_record; ++i) {
       double *rec = record + (size_t)(i - 1) * neq;
       for (int k = lane; k < n; k += 64) rec[k] = c.y[k];
-      if (lane == 0) rec[n] = g_wc.Tgas;
+      if (lane == 0) rec[n] = ET ? (double)g_T.y : (double)g_wc.Tgas;
     }
   }
   dev_mark(c, 401);
@@ -768,6 +976,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
   CellResult R{};
   R.t_final = t; R.t_good = e.t_good; R.isav = e.isav; R.quality = qual; R.nerr = e.nerr; R.nrec_real = nrr;
   R.nst = e.nst_acc; R.nfe = e.nfe_acc; R.nje = e.nje_acc; R.nlu = e.nlu_acc; R.qsum = s.qsum; R.nfail = s.nfail; R.errc = e.errc;
+  if constexpr (ET) { R.T_good = g_Th.T_good; R.evolT_end = g_T.evolT; }
   return R;
 }
 

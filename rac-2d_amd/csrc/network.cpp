@@ -511,6 +511,16 @@ void build_reference_layout(HostNetwork &net) {
       if (it == col[j].end()) throw std::runtime_error("pattern entry outside the reference's pattern");
       net.ref_kref[q] = start[j] + (int)(it - col[j].begin());
     }
+  // the T row (at the ten special species) and the T column in that storage (evolT: engine_integrate.hpp, ISTATE = 3)
+  for (int k = 0; k < 10; ++k) {
+    net.ref_kref_Trow[k] = -1;
+    if (net.idx10[k] > 0) {
+      const int j = net.idx10[k] - 1;
+      const auto it = std::find(col[j].begin(), col[j].end(), nS);
+      if (it != col[j].end()) net.ref_kref_Trow[k] = start[j] + (int)(it - col[j].begin());
+    }
+  }
+  net.ref_kref_Tcol0 = start[nS];
   // IWORK(17) (LENRW) as the reference's DLSODES reports it for the networks shipped in data/ (measured with
   // oracle/_ref/ref_driver, section '# workspace'); it depends on YSMP's compressed index storage and cannot be derived
   // without it.  Other networks: racgpu_network_set_reference_lenrw, or 0 = the saved P is taken to survive ISTATE = 3.

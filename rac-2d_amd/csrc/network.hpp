@@ -84,6 +84,7 @@ struct HostNetwork {
   // with the RWORK length the reference allocates (20 + 4 NNZ + 28 NEQ), overlaps the tail of the saved P.
   int ref_nnz0 = 0, ref_nnz1 = 0;   // entries of the reference's mask / of IAN-JAN with the diagonal added
   std::vector<int> ref_kref;        // per entry of Jrow (CSC order): 0-based position in that storage
+  int ref_kref_Trow[10] = {0}, ref_kref_Tcol0 = 0; // the same for the T row's entries (columns of idx10) and the first entry of the T column
   int ref_lenrw = 0;                // IWORK(17) of the reference's DLSODES for this network (0 = unknown: P is taken to survive)
 
   int species_index(const std::string &name) const; // 1-based, 0 if absent

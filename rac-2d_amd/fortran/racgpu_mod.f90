@@ -19,7 +19,7 @@ module racgpu
             racgpu_set_cost_hints, racgpu_set_team_threshold, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
   public :: racgpu_error_string, chemsol_to_c, c_string
 
-  integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 20, RACGPU_NOUT = 3, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
+  integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 20, RACGPU_NOUT = 5, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
   integer, parameter :: RACGPU_F_RECTIFY = 1
 
   ! struct racgpu_params (include/racgpu.h)

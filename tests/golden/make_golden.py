@@ -60,16 +60,21 @@ def read_cell(fn):
 
 
 def run_ref(network, initial, cells, rtol, t_max, steps_reset, dump_jac, solve=1, atol=1e-30, mxstep=6000, nlocal_iter=1, tol_j=1,
-            y_override=None, special_gH_mobi=False, dump_analysis=0):
-    """y_override: list of (cell (1-based), species (1-based), value) applied to the initial condition."""
+            y_override=None, special_gH_mobi=False, dump_analysis=0, hc=None, may_switch_T=1):
+    """y_override: list of (cell (1-based), species (1-based), value) applied to the initial condition.
+    hc: heating/cooling records [ncell, 28] -> the run is made with the gas temperature co-evolving (evolT)."""
     with tempfile.TemporaryDirectory() as td:
         np.savetxt(os.path.join(td, "cells.txt"), cells, fmt="%.17e")
         ov = ""
+        if hc is not None:
+            np.savetxt(os.path.join(td, "hc.txt"), hc, fmt="%.17e")
+            ov += " evolT=1\n may_switch_T=%d\n hc_file='%s'\n enthalpy='Species_enthalpy.dat'\n transitions_dir='/root/reference/transitions/'\n" % (
+                may_switch_T, os.path.join(td, "hc.txt"))
         if y_override:
             with open(os.path.join(td, "override.txt"), "w") as f:
                 for c, sp, v in y_override:
                     f.write("%d %d %.17e\n" % (c, sp, v))
-            ov = " y_override='%s'\n" % os.path.join(td, "override.txt")
+            ov += " y_override='%s'\n" % os.path.join(td, "override.txt")
         with open(os.path.join(td, "run.nml"), "w") as f:
             f.write("&ref_run\n chem_dir='%s'\n network='%s'\n initial='%s'\n out_dir='%s'\n cell_file='%s'\n"
                     " ncell=%d\n rtol=%.17e\n atol=%.17e\n dt_first_step=1D-8\n ratio_tstep=1.1D0\n t_max=%.17e\n"
@@ -91,6 +96,10 @@ def run_ref(network, initial, cells, rtol, t_max, steps_reset, dump_jac, solve=1
             pattern=np.loadtxt(os.path.join(td, "pattern.txt"), dtype=np.int32),
             y0=np.loadtxt(os.path.join(td, "y0.txt")),
         )
+        if os.path.exists(os.path.join(td, "heat.txt")):  # chem_net%iReacWithHeat, %heat (evolT runs)
+            rows = open(os.path.join(td, "heat.txt")).read().splitlines()[1:]
+            meta["heat_rxn"] = np.array([int(l[:8]) for l in rows], dtype=np.int32)
+            meta["heat_val"] = np.array([float(l[8:]) for l in rows])
     return out, meta
 
 
@@ -275,6 +284,10 @@ def main_grid64():
     out = dict(network_file=network, initial_file=initial, grid_idx=idx, cells=cells, cells_ulp=cells_ulp,
                yend=np.array([c["yend"] for c in cfg]), scalars=np.array([c["scalars"][:3] for c in cfg]), errcodes=ec_cfg,
                stats=np.array([c["stats"] for c in cfg]),
+               # rate coefficients of every fourth of them and dy/dt at every end state: the cells span T 9..3300 K, the fixture cells of
+               # the per-network files only 10, 50, 300 and 2000 K
+               rates_cells=np.arange(0, len(idx), 4), rates=np.array([cfg[k]["rates"] for k in range(0, len(idx), 4)]),
+               ydotend=np.array([c["ydotend"] for c in cfg]),
                yend_ulp=np.array([c["yend"] for c in ulp]), scalars_ulp=np.array([c["scalars"][:3] for c in ulp]), errcodes_ulp=ec_ulp,
                yend_tight=np.array([c["yend"] for c in tight]), scalars_tight=np.array([c["scalars"][:3] for c in tight]), errcodes_tight=ec_t,
                yend_tighter=np.array([c["yend"] for c in tighter]), scalars_tighter=np.array([c["scalars"][:3] for c in tighter]))
@@ -290,6 +303,66 @@ def main_grid64():
         tt.append(np.max(np.abs(yt[i][m] - ytt[i][m]) / ytt[i][m]))
     print("wrote", fn, os.path.getsize(fn) // 1024, "KiB; 1-ulp floor: median %.1e max %.1e; 1e-8 vs 1e-10: median %.1e max %.1e; NERR cfg %d ulp %d tight %d"
           % (np.median(fl), np.max(fl), np.median(tt), np.max(tt), out["scalars"][:, 2].sum(), out["scalars_ulp"][:, 2].sum(), out["scalars_tight"][:, 2].sum()))
+
+
+def main_evolT():
+    """tests/golden/evolT_grain.npz: gas temperature co-evolving with the chemistry (chemsol_params%evolT) on eight cells of the configs[2]
+    grid with their heating/cooling records (cells.andrews_grid_hc): dy/dt incl. dT/dt and the 29 heating/cooling values at the
+    initial state and at the end state, the finite-difference T row / T column of the Jacobian at the initial state, and the run
+    itself: end state incl. T, T(t) of every record, whether the T-freeze test fired; the same with n_gas moved by one ulp (the
+    noise floor) and at RTOL 1e-8."""
+    C = importlib.import_module("rac-2d_amd.cells")
+    grid, r, z = C.andrews_grid(return_geometry=True)
+    hcg = C.andrews_grid_hc(grid, r, z)
+    network, initial = "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "ini_abund_waterice_loMetal.dat"
+    idx = np.array([20, 452, 3817, 8696, 11412, 14998, 15952, 19233])
+    cells, hc = grid[idx], hcg[idx]
+    cfg, meta = run_ref(network, initial, cells, 1e-4, 1e6, 50, 1, hc=hc)
+    nS = len(meta["species"]); NEQ = nS + 1
+    cells_ulp = cells.copy()
+    cells_ulp[:, 2] = np.nextafter(cells_ulp[:, 2], np.inf)
+    cells_ulp[:, 5] = cells_ulp[:, 2] * cells_ulp[:, 6]
+    hc_ulp = hc.copy(); hc_ulp[:, C.H_N_DUSTS] = cells_ulp[:, 5]
+    ulp, _ = run_ref(network, initial, cells_ulp, 1e-4, 1e6, 50, 0, hc=hc_ulp)
+    tight, _ = run_ref(network, initial, cells, 1e-8, 1e6, 50, 0, hc=hc)
+    IA, JA = meta["pattern"][:NEQ + 1], meta["pattern"][NEQ + 1:]
+    # the T row (entries of row NEQ in the columns of the ten special species) and the T column of jac0
+    ten = ["H2", "H", "E-", "C", "C+", "O", "O2", "CO", "H2O", "OH"]
+    idx10 = [meta["species"].index(s) + 1 for s in ten]
+    trow, tcol = [], []
+    for c in cfg:
+        j0 = c["jac0"]
+        row = []
+        for j in idx10:
+            q = [k for k in range(IA[j - 1] - 1, IA[j] - 1) if JA[k] == NEQ]
+            row.append(j0[q[0]])
+        trow.append(row)
+        col = np.zeros(NEQ)
+        for k in range(IA[NEQ - 1] - 1, IA[NEQ] - 1):
+            col[JA[k] - 1] = j0[k]
+        tcol.append(col)
+    def pad(rows):  # n_record differs from cell to cell (per-cell t_max): NaN-padded to the longest
+        n = max(len(r) for r in rows)
+        return np.array([np.r_[r, np.full(n - len(r), np.nan)] for r in rows])
+    out = dict(network_file=network, initial_file=initial, grid_idx=idx, cells=cells, hc=hc, cells_ulp=cells_ulp, hc_ulp=hc_ulp,
+               species=np.array(meta["species"]), y0=meta["y0"], idx10=np.array(idx10),
+               ydot0=np.array([c["ydot0"] for c in cfg]), hc0=np.array([c["hc0"] for c in cfg]), trow0=np.array(trow), tcol0=np.array(tcol),
+               yend=np.array([c["yend"] for c in cfg]), scalars=np.array([c["scalars"][:3] for c in cfg]), stats=np.array([c["stats"] for c in cfg]),
+               touts=pad([c["touts"] for c in cfg]), Trecord=pad([c["Trecord"] for c in cfg]),
+               evolTend=np.array([c["evolTend"][0] for c in cfg]), ydotend=np.array([c["ydotend"] for c in cfg]), hcend=np.array([c["hcend"] for c in cfg]),
+               yend_ulp=np.array([c["yend"] for c in ulp]), scalars_ulp=np.array([c["scalars"][:3] for c in ulp]), evolTend_ulp=np.array([c["evolTend"][0] for c in ulp]),
+               yend_tight=np.array([c["yend"] for c in tight]), scalars_tight=np.array([c["scalars"][:3] for c in tight]),
+               Trecord_tight=pad([c["Trecord"] for c in tight]), evolTend_tight=np.array([c["evolTend"][0] for c in tight]),
+               heat_rxn=meta["heat_rxn"], heat_val=meta["heat_val"])
+    fn = os.path.join(HERE, "evolT_grain.npz")
+    np.savez_compressed(fn, **out)
+    for i in range(len(idx)):
+        ye, yu, yt = out["yend"][i], out["yend_ulp"][i], out["yend_tight"][i]
+        m = ye[:nS] >= 1e-6
+        print("cell %5d T0 %7.1f -> Tend %8.3f (ulp twin %8.3f, RTOL 1e-8 %8.3f) evolTend %d  q %d NERR %d  floor %.1e  dT/dt0 %.3e K/yr" % (
+            idx[i], cells[i, 0], ye[nS], yu[nS], yt[nS], out["evolTend"][i], out["scalars"][i, 1], out["scalars"][i, 2],
+            np.max(np.abs(ye[:nS][m] - yu[:nS][m]) / ye[:nS][m]), out["ydot0"][i, nS]))
+    print("wrote", fn, os.path.getsize(fn) // 1024, "KiB")
 
 
 def main_shielding():
@@ -321,6 +394,8 @@ if __name__ == "__main__":
         main_policy()
     elif len(sys.argv) > 1 and sys.argv[1] == "grid64":
         main_grid64()
+    elif len(sys.argv) > 1 and sys.argv[1] == "evolT":
+        main_evolT()
     else:
         main()
         main_policy()

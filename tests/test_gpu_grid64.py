@@ -86,3 +86,36 @@ def test_grid_cells_tight_tolerance_pair(racgpu, grid64):
     assert (out["t_final"] == g["scalars_tight"][:, 0]).all()
     assert (out["quality"] == g["scalars_tight"][:, 1].astype(int)).all()
     assert (out["stats"][:, racgpu.S_NERR] == g["scalars_tight"][:, 2]).all()  # RTOL 1e-8: error returns equal cell by cell
+
+
+def test_grid_cells_rate_coefficients(racgpu, grid64):
+    """chem_cal_rates at the grid's own temperatures (9 ... 3300 K): 1e-12 relative, same zero pattern (duplicate pruning, ranges)."""
+    g, net, y0 = grid64
+    sub = g["rates_cells"]
+    k = net.cal_rates(racgpu.default_params(), g["cells"][sub])
+    ref = g["rates"]
+    assert ((k == 0) == (ref == 0)).all()
+    nz = ref != 0
+    assert np.max(np.abs(k[nz] - ref[nz]) / np.abs(ref[nz])) <= 1e-12
+
+
+def test_grid_cells_rhs_at_the_end_states(racgpu, grid64):
+    """chem_ode_f at the reference's end state of every cell: within 1e-9 of the largest flux touching each species."""
+    g, net, y0 = grid64
+    nS = net.nSpecies
+    p = racgpu.default_params()
+    rx = net.reactions()
+    y = np.ascontiguousarray(g["yend"][:, :nS])
+    yd = net.ode_f(p, g["cells"], y)
+    k = net.cal_rates(p, g["cells"])
+    for c in range(len(g["cells"])):
+        ya = np.where(rx["reac"][:, 0] > 0, y[c][np.maximum(rx["reac"][:, 0] - 1, 0)], 0.0)
+        yb = np.where((rx["reac"][:, 1] > 0) & np.isin(rx["itype"], (5, 6, 21, 64)), y[c][np.maximum(rx["reac"][:, 1] - 1, 0)], 1.0)
+        fl = np.abs(k[c] * ya * yb)
+        scale = np.zeros(nS)
+        for cols in (rx["reac"], rx["prod"]):
+            for s in range(cols.shape[1]):
+                m = cols[:, s] > 0
+                np.maximum.at(scale, cols[m, s] - 1, fl[m])
+        err = np.abs(yd[c] - g["ydotend"][c][:nS])
+        assert (err <= 1e-9 * np.maximum(scale, 1e-300) + 1e-300).all(), (int(g["grid_idx"][c]), float(err.max()))

@@ -33,7 +33,7 @@ for rtol, key in ((1e-4, "yend"), (1e-8, "yend_tight")):
             sc = g["scalars_tight"][c]
         et, spt = worst(out["y"][c], g["yend_tighter"][c][:nS])
         ec = int(out["stats"][c, R.S_ERRCODES])
-        print("cell %5d T %7.1f n %.2e  err %.2e (%-8s X=%.1e)  ref-own %.2e  vs-1e-10 %.2e (%s)  NERR gpu %d [%d %d %d %d] ref %d  NST %d  q %d/%d  tf %s" % (
+        print("cell %5d T %7.1f n %.2e  err %.2e (%-8s X=%.1e)  ref-own %.2e  vs-1e-10 %.2e (%s)  NERR gpu %d [%d %d %d %d] ref %d  NST %d NFE %d NJE %d NLU %d fail %d  q %d/%d  tf %s" % (
             g["grid_idx"][c], g["cells"][c, 0], g["cells"][c, 2], e, names[sp], ref[sp], fl, et, names[spt], out["stats"][c, R.S_NERR],
-            ec & 0xffff, (ec >> 16) & 0xffff, (ec >> 32) & 0xffff, (ec >> 48) & 0xffff, sc[2], out["stats"][c, 0], out["quality"][c], sc[1],
+            ec & 0xffff, (ec >> 16) & 0xffff, (ec >> 32) & 0xffff, (ec >> 48) & 0xffff, sc[2], out["stats"][c, 0], out["stats"][c, 1], out["stats"][c, 2], out["stats"][c, 3], out["stats"][c, 7], out["quality"][c], sc[1],
             out["t_final"][c] == sc[0]))
