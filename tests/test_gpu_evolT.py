@@ -30,7 +30,7 @@ def ev(racgpu):
 
 
 def _terms_close(got, ref, what):
-    assert ((got[1:] == 0) == (ref[1:] == 0)).all(), (what, [racgpu_name for racgpu_name in np.nonzero((got[1:] == 0) != (ref[1:] == 0))[0]])
+    assert ((got[1:] == 0) == (ref[1:] == 0)).all(), (what, np.nonzero((got[1:] == 0) != (ref[1:] == 0))[0])
     nz = ref[1:] != 0
     rel = np.abs(got[1:][nz] - ref[1:][nz]) / np.abs(ref[1:][nz])
     assert rel.max() <= 1e-12, (what, int(np.argmax(rel)), float(rel.max()))
