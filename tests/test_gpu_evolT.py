@@ -43,6 +43,7 @@ def test_heating_cooling_terms_and_rhs_match_reference(racgpu, ev):
     nS = net.nSpecies
     p = racgpu.default_params()
     kB, spy = 1.3806503e-16, 3600.0 * 24.0 * 365.0
+    rx = net.reactions()
     for tag_y, tag_f, tag_h in (("y0", "ydot0", "hc0"), ("yend", "ydotend", "hcend")):
         if tag_y == "y0":
             y = np.hstack([net.init_abundances(g["y0"], g["cells"]), g["cells"][:, :1]])
@@ -53,10 +54,18 @@ def test_heating_cooling_terms_and_rhs_match_reference(racgpu, ev):
             _terms_close(out["terms"][c], g[tag_h][c], (tag_h, int(g["grid_idx"][c])))
             scale = np.sum(np.abs(g[tag_h][c][1:])) * spy / (g["cells"][c, 2] * kB)
             assert abs(out["ydot"][c, nS] - g[tag_f][c][nS]) <= 1e-12 * scale, (tag_f, c, out["ydot"][c, nS], g[tag_f][c][nS])
-            # species part: the fixed-T bound of test_gpu_parity (1e-9 of the largest flux into or out of the species) holds a fortiori
-            # for the sum of |ydot|; checked here against the largest |ydot| of the cell, entry by entry where it matters
-            big = np.max(np.abs(g[tag_f][c][:nS]))
-            assert np.max(np.abs(out["ydot"][c, :nS] - g[tag_f][c][:nS])) <= 1e-9 * big * 1e3, (tag_f, c)
+            # species part: within 1e-9 of the largest flux touching each species (the bound of test_gpu_parity)
+            k = net.cal_rates(p, np.r_[g["cells"][c][:0], [y[c, nS]], g["cells"][c][1:]][None, :])[0]
+            ya = np.where(rx["reac"][:, 0] > 0, y[c][np.maximum(rx["reac"][:, 0] - 1, 0)], 0.0)
+            yb = np.where((rx["reac"][:, 1] > 0) & np.isin(rx["itype"], (5, 6, 21, 64)), y[c][np.maximum(rx["reac"][:, 1] - 1, 0)], 1.0)
+            fl = np.abs(k * ya * yb)
+            scale = np.zeros(nS)
+            for cols in (rx["reac"], rx["prod"]):
+                for s_ in range(cols.shape[1]):
+                    m = cols[:, s_] > 0
+                    np.maximum.at(scale, cols[m, s_] - 1, fl[m])
+            err = np.abs(out["ydot"][c, :nS] - g[tag_f][c][:nS])
+            assert (err <= 1e-9 * np.maximum(scale, 1e-300) + 1e-300).all(), (tag_f, int(g["grid_idx"][c]), float(err.max()))
 
 
 def test_jacobian_T_row_and_column_match_reference(racgpu, ev):

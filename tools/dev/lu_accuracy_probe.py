@@ -16,6 +16,7 @@ nS = net.nSpecies
 colptr, rowidx = net.jac_pattern()
 idx = list(g["grid_idx"])
 p = R.default_params(); p.RTOL = 1e-8
+dump = {}
 for ci in (39, 351, 9711, 2223, 663, 12207):
     k = idx.index(ci)
     cell = g["cells"][k:k + 1]
@@ -35,5 +36,9 @@ for ci in (39, 351, 9711, 2223, 663, 12207):
         # one refinement step through the engine's own factors
         dx = net.newton_solve(p, cell, y, gamma, (-r)[None, :])[0]
         x2 = x + dx
+        if ci in (39, 2223) and gamma in (1.0, 1e2, 1e4):
+            dump["c%d_g%g" % (ci, gamma)] = np.concatenate([x, b])
+            dump["c%d_J" % ci] = vals; dump["c%d_y" % ci] = y[0]; dump["c%d_w" % ci] = w
         print("cell %5d gamma %.0e  |x|w %.2e  |x - x_piv|w %.2e  |Px-b|w %.2e   refined: |x2 - x_piv|w %.2e  |Px2-b|w %.2e   pivoted |Px-b|w %.2e  max|x| %.2e" % (
             ci, gamma, wrms(xs), wrms(x - xs), wrms(r), wrms(x2 - xs), wrms(P @ x2 - b), wrms(P @ xs - b), np.max(np.abs(xs))))
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", "lu_accuracy_dump.npz"), colptr=colptr, rowidx=rowidx, **dump)
