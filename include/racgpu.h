@@ -145,6 +145,9 @@ int racgpu_reaction_rows(const racgpu_network *, double *ABC, double *T_range, c
 /* CSC pattern of the species-block Jacobian: colptr[nS+1], rowidx[nnzJ], 1-based */
 int racgpu_jac_pattern(const racgpu_network *, int32_t *colptr, int32_t *rowidx);
 
+/* elimination order of the species-block LU: perm[new] = old species index (1-based); *first_dense = first position (1-based) of
+ * the trailing block that is factored as a dense matrix.  The reference recomputes its own (YSMP ODRV) inside DLSODES. */
+int racgpu_lu_ordering(const racgpu_network *, int32_t *perm, int32_t *first_dense);
 /* chem_load_initial_abundances (src/chemistry.f90:1978-2024): y0[nS], neutralised and renormalised to sum(H)=1 */
 int racgpu_load_initial_abundances(const racgpu_network *, const char *path, double *y0);
 void racgpu_params_default(racgpu_params *);          /* type defaults + inp/template_configure.dat values */
@@ -292,6 +295,24 @@ int64_t racgpu_last_parked_cells(racgpu_network *);
 int64_t racgpu_workspace_bytes_per_cell(const racgpu_network *);
 /* HIP-event time of the last racgpu_solve_batch kernel on its stream, milliseconds (-1 if none) */
 double racgpu_last_kernel_ms(const racgpu_network *);
+
+/* ---- one host process, N GPUs of one node (BASELINE.json north_star: "cells shard embarrassingly across the 8 GPUs of one node, with a
+ * single RCCL gather over xGMI at output").  The reference has no counterpart (its sweep is a serial loop, src/disk.f90:864-938).
+ * racgpu_multi_create loads the network once per device (devices == NULL: 0 .. ndev-1) and opens an RCCL communicator over them
+ * (ncclCommInitAll; librccl.so is loaded on first use).  racgpu_multi_calc_cells = racgpu_calc_cells on host buffers with the cells
+ * dealt over the devices -- in order of decreasing cost (cost == NULL: index order), round-robin, so that every device gets the same
+ * mix -- one host thread per device, and ONE ncclAllGather of the result rows [y | t_final | quality | stats | cell_out] at the end,
+ * after which every device holds every cell's result; device 0's copy is returned.  Results do not depend on ndev or on the dealing. */
+typedef struct racgpu_multi racgpu_multi;
+racgpu_multi *racgpu_multi_create(const char *network_path, int ndev, const int *devices);
+void racgpu_multi_destroy(racgpu_multi *);
+int racgpu_multi_ndev(const racgpu_multi *);
+racgpu_network *racgpu_multi_network(racgpu_multi *, int i); /* device i's handle (e.g. for racgpu_network_set_reference_lenrw) */
+const char *racgpu_multi_last_error(void);
+/* the dealing rule by itself (host only): owner[c] = device of cell c, position[c] = its place in that device's batch */
+int racgpu_multi_deal(int ndev, int64_t ncell, const double *cost, int32_t *owner, int32_t *position);
+int racgpu_multi_calc_cells(racgpu_multi *, const racgpu_params *, int32_t nlocal_iter, int64_t ncell, const double *cells, double *y,
+                            double *t_final, int32_t *quality, int64_t *stats, double *cell_out, const double *cost);
 
 #ifdef __cplusplus
 }

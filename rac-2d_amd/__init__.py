@@ -43,11 +43,13 @@ HC_TERM_NAMES = ("hc_net_rate", "heating_photoelectric_small_grain", "heating_fo
 ABI_SYMBOLS = [
     "racgpu_last_error", "racgpu_device_count", "racgpu_network_load", "racgpu_network_destroy",
     "racgpu_network_dims", "racgpu_network_set_reference_lenrw", "racgpu_network_reference_lenrw", "racgpu_species_name", "racgpu_species_index", "racgpu_reactions",
-    "racgpu_species_attrs", "racgpu_species_elements", "racgpu_reaction_rows", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
+    "racgpu_lu_ordering", "racgpu_species_attrs", "racgpu_species_elements", "racgpu_reaction_rows", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
     "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_column_sweep", "racgpu_set_co_shielding_table", "racgpu_rectify_abundances",
     "racgpu_hc_config_default", "racgpu_heating_cooling_load", "racgpu_heat_reactions", "racgpu_evolT_hooks", "racgpu_evolT_solve_batch",
+    "racgpu_multi_create", "racgpu_multi_destroy", "racgpu_multi_ndev", "racgpu_multi_network", "racgpu_multi_last_error", "racgpu_multi_deal",
+    "racgpu_multi_calc_cells",
     "racgpu_set_cost_hints", "racgpu_set_team_threshold", "racgpu_last_team_cells", "racgpu_last_parked_cells", "racgpu_workspace_bytes_per_cell", "racgpu_last_kernel_ms",
 ]
 
@@ -109,6 +111,7 @@ def lib():
     L.racgpu_species_index.argtypes = [vp, C.c_char_p]
     L.racgpu_reactions.argtypes = [vp, ip, ip, ip, ip, ip, ip]
     L.racgpu_species_attrs.argtypes = [vp, dp, dp, dp, ip, ip]
+    L.racgpu_lu_ordering.argtypes = [vp, ip, ip]
     L.racgpu_jac_pattern.argtypes = [vp, ip, ip]
     L.racgpu_species_elements.argtypes = [vp, ip]
     L.racgpu_reaction_rows.argtypes = [vp, dp, dp, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -143,6 +146,15 @@ def lib():
     L.racgpu_heat_reactions.argtypes = [vp, ip, ip, dp]
     L.racgpu_evolT_hooks.argtypes = [vp, pp, dp, dp, C.c_int64, dp, dp, dp, vp, vp]
     L.racgpu_evolT_solve_batch.argtypes = [vp, pp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int]
+    L.racgpu_multi_create.restype = vp
+    L.racgpu_multi_create.argtypes = [C.c_char_p, C.c_int, ip]
+    L.racgpu_multi_destroy.argtypes = [vp]
+    L.racgpu_multi_ndev.argtypes = [vp]
+    L.racgpu_multi_network.restype = vp
+    L.racgpu_multi_network.argtypes = [vp, C.c_int]
+    L.racgpu_multi_last_error.restype = C.c_char_p
+    L.racgpu_multi_deal.argtypes = [C.c_int, C.c_int64, dp, ip, ip]
+    L.racgpu_multi_calc_cells.argtypes = [vp, pp, C.c_int32, C.c_int64, dp, dp, dp, ip, lp, dp, dp]
     L.racgpu_set_team_threshold.restype = C.c_int
     L.racgpu_set_team_threshold.argtypes = [vp, C.c_double]
     L.racgpu_last_team_cells.restype = C.c_int64
@@ -180,6 +192,49 @@ def default_hc_config():
     c = HcConfig()
     lib().racgpu_hc_config_default(C.byref(c))
     return c
+
+
+def multi_deal(ndev, ncell, cost=None):
+    """racgpu_multi_deal: (owner [ncell], position [ncell]) of the single-process multi-GPU entry point's dealing rule (host only)."""
+    owner = np.zeros(ncell, np.int32); pos = np.zeros(ncell, np.int32)
+    c = None if cost is None else np.ascontiguousarray(cost, np.float64)
+    _check(lib().racgpu_multi_deal(ndev, ncell, None if c is None else _dp(c), _ip(owner), _ip(pos)))
+    return owner, pos
+
+
+class MultiGPU:
+    """racgpu_multi: one process, ndev GPUs of one node, one RCCL all-gather of the results (include/racgpu.h)."""
+
+    def __init__(self, path, ndev, devices=None):
+        d = None if devices is None else np.ascontiguousarray(devices, np.int32)
+        self._m = lib().racgpu_multi_create(os.fsencode(path), ndev, None if d is None else _ip(d))
+        if not self._m:
+            raise RacgpuError(lib().racgpu_multi_last_error().decode())
+        self.ndev = lib().racgpu_multi_ndev(self._m)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            lib().racgpu_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def calc_cells(self, params, cell_records, y, nlocal_iter=1, cost=None):
+        cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
+        n = cr.shape[0]
+        nS = y.shape[-1]
+        y = np.array(y, np.float64).reshape(n, nS).copy()
+        tf = np.zeros(n); q = np.zeros(n, np.int32); st = np.zeros((n, NSTAT), np.int64); co = np.zeros((n, NOUT))
+        c = None if cost is None else np.ascontiguousarray(cost, np.float64)
+        rc = lib().racgpu_multi_calc_cells(self._m, C.byref(params), nlocal_iter, n, _dp(cr), _dp(y), _dp(tf), _ip(q),
+                                           st.ctypes.data_as(C.POINTER(C.c_int64)), _dp(co), None if c is None else _dp(c))
+        if rc != 0:
+            raise RacgpuError(lib().racgpu_multi_last_error().decode())
+        return dict(y=y, t_final=tf, quality=q, stats=st, cell_out=co)
 
 
 def device_count():
@@ -262,6 +317,12 @@ class Network:
         colptr = np.zeros(self.nSpecies + 1, np.int32); rowidx = np.zeros(self.nnzJ, np.int32)
         _check(lib().racgpu_jac_pattern(self._h, _ip(colptr), _ip(rowidx)))
         return colptr, rowidx
+
+    def lu_ordering(self):
+        """(perm [nS] 1-based: perm[new] = old, first position (1-based) of the dense trailing block)"""
+        perm = np.zeros(self.nSpecies, np.int32); fd = C.c_int32()
+        _check(lib().racgpu_lu_ordering(self._h, _ip(perm), C.byref(fd)))
+        return perm, fd.value
 
     def load_initial_abundances(self, path):
         y0 = np.zeros(self.nSpecies)

@@ -350,7 +350,7 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
           if (useful) o[RACGPU_O_TGAS] = R.T_good;
           o[RACGPU_O_EVOLT_END] = (double)R.evolT_end;
           if (N.r_h2form >= 0) o[RACGPU_O_R_H2_FORM] = g_T.rh2;
-        } else if (useful) o[RACGPU_O_TGAS] = cp[RACGPU_P_TGAS];
+        } else { if (useful) o[RACGPU_O_TGAS] = cp[RACGPU_P_TGAS]; o[RACGPU_O_EVOLT_END] = 0.0; }
       }
       if (A.stats) {
         long long *s = A.stats + (size_t)cell * RACGPU_NSTAT;
@@ -1041,6 +1041,13 @@ int racgpu_jac_pattern(const racgpu_network *h, int32_t *colptr, int32_t *rowidx
   if (!h) return fail("null network");
   if (colptr) for (int j = 0; j <= h->net.nS; ++j) colptr[j] = h->net.Jcolptr[j] + 1;
   if (rowidx) for (size_t q = 0; q < h->net.Jrow.size(); ++q) rowidx[q] = h->net.Jrow[q] + 1;
+  return 0;
+}
+
+int racgpu_lu_ordering(const racgpu_network *h, int32_t *perm, int32_t *first_dense) {
+  if (!h) return fail("null network");
+  if (perm) for (int i = 0; i < h->net.nS; ++i) perm[i] = h->net.sym.perm[i] + 1;
+  if (first_dense) *first_dense = h->net.sym.ns + 1;
   return 0;
 }
 

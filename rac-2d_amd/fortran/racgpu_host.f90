@@ -1,12 +1,20 @@
 ! racgpu_host.f90 -- Fortran host for the batched GPU chemistry solve.
 !
-!   racgpu_host <configure.dat> <cells.txt> <out_prefix> [nlocal_iter [restart.bin]]
+!   racgpu_host <configure.dat> <cells.txt> <out_prefix> [nlocal_iter [restart.bin|- [ndev [hc.txt]]]]
 !
 !   nlocal_iter  (default 1) a_disk_iter_params%nlocal_iter of the reference's &iteration_configure: > 1 runs calc_this_cell's
 !                local-iteration loop (retries from t_final with looser tolerance policies, reference src/disk.f90:1651-1791)
 !                through racgpu_calc_cells
 !   restart.bin  a chemical_data_iter_NNNN.bin of a previous run (reference src/data_dump.f90:88-162, read back as
 !                back_cells_chemical_data_load does): the cells start from its abundances instead of the initial-abundance file
+!                ('-': none)
+!   ndev         (default 0) >= 1: the cells are dealt over ndev GPUs of this node by ONE process (racgpu_multi_calc_cells:
+!                one host thread per device, one RCCL all-gather of the results); 0: the single-device entry points
+!   hc.txt       per-cell heating/cooling records (RACGPU_NHC numbers per row, include/racgpu.h RACGPU_H_*): the gas temperature
+!                co-evolves with the chemistry in every cell with en_gain_tot > 0 (chemsol_params%evolT, reference
+!                src/disk.f90:2066-2073); the switches come from &heating_cooling_configure of <configure.dat> if it has one, the
+!                enthalpy file from chemsol_params%filename_species_enthalpy, the ion look-up tables from
+!                heating_cooling_config%dir_transition_rates, the Neufeld tables from <chem_files_dir>/neufeld_cooling_tables.dat
 !
 ! Plays the part of rac-2d's cell sweep (do_chemical_stuff -> calc_this_cell, reference src/disk.f90:864-938,
 ! 1629-1801) for a table of frozen per-cell input records: reads the reference's own `&chemistry_configure`
@@ -26,8 +34,12 @@ program racgpu_host
   use, intrinsic :: iso_c_binding
   use racgpu
   implicit none
-  character(len=512) :: f_conf, f_cells, prefix, path, f_restart, argbuf
-  integer :: nlocal_iter
+  character(len=512) :: f_conf, f_cells, prefix, path, f_restart, argbuf, f_hc
+  integer :: nlocal_iter, ndev
+  type(c_ptr) :: multi
+  type(racgpu_hc_config_t) :: hcc
+  real(c_double), allocatable, target :: hc(:, :)
+  logical :: evolT
   real(c_double), allocatable, target :: cell_out(:, :)
   real(c_double), allocatable :: col20(:)
   character(kind=c_char), dimension(32) :: nbuf
@@ -59,6 +71,15 @@ program racgpu_host
     read(argbuf, *) nlocal_iter
   end if
   if (command_argument_count() >= 5) call get_command_argument(5, f_restart)
+  if (trim(f_restart) == '-') f_restart = ''
+  ndev = 0
+  if (command_argument_count() >= 6) then
+    call get_command_argument(6, argbuf)
+    read(argbuf, *) ndev
+  end if
+  f_hc = ''
+  if (command_argument_count() >= 7) call get_command_argument(7, f_hc)
+  evolT = len_trim(f_hc) > 0
 
   open(newunit=fu, file=trim(f_conf), status='old', action='read')
   call chemistry_configure_read(fu, ios)
@@ -68,6 +89,12 @@ program racgpu_host
     stop 1
   end if
   call chemsol_to_c(p)
+  if (evolT) then ! the reference reads the namelists in a fixed order (src/configure.f90:27-38); a file without this one keeps the defaults
+    open(newunit=fu, file=trim(f_conf), status='old', action='read')
+    call heating_cooling_configure_read(fu, ios)
+    close(fu)
+    call heating_cooling_to_c(hcc, 0.01D0, .true.)
+  end if
 
   if (racgpu_device_count() < 1) then
     write(*, '(A)') 'racgpu_host: no HIP device visible (the racgpu path has no CPU fallback)'
@@ -113,6 +140,24 @@ program racgpu_host
   end do
   close(fu)
 
+  if (evolT) then
+    allocate(hc(RACGPU_NHC, ncell))
+    open(newunit=fu, file=trim(f_hc), status='old', action='read')
+    do i = 1, ncell
+      read(fu, *) hc(:, i)
+    end do
+    close(fu)
+    rc = racgpu_heating_cooling_load(net, hcc, &
+           c_string(trim(chemsol_params%chem_files_dir) // trim(chemsol_params%filename_species_enthalpy)), &
+           c_string(trim(chemsol_params%chem_files_dir) // 'neufeld_cooling_tables.dat'), &
+           c_string(trim(heating_cooling_config%dir_transition_rates) // trim(heating_cooling_config%filename_NII)), &
+           c_string(trim(heating_cooling_config%dir_transition_rates) // trim(heating_cooling_config%filename_SiII)), &
+           c_string(trim(heating_cooling_config%dir_transition_rates) // trim(heating_cooling_config%filename_FeII)))
+    if (rc /= 0) then
+      write(*, '(A)') 'racgpu_heating_cooling_load: ' // trim(racgpu_error_string())
+      stop 1
+    end if
+  end if
   rc = racgpu_init_abundances(net, y0, cells, int(ncell, c_int64_t), y)
   allocate(cell_out(RACGPU_NOUT, ncell), col20(20))
   cell_out = 0D0
@@ -131,7 +176,34 @@ program racgpu_host
     allocate(record(nS + 1, n_record, ncell), touts(n_record, ncell))
     prec = c_loc(record); ptouts = c_loc(touts)
   end if
-  if (nlocal_iter > 1) then
+  if (ndev >= 1) then
+    ! one process, ndev GPUs: the cells dealt over the devices, one RCCL all-gather of the results (racgpu_multi_calc_cells)
+    if (evolT .or. chemsol_params%flag_chem_evol_save) then
+      write(*, '(A)') 'racgpu_host: the multi-GPU entry point runs the fixed-T local-iteration loop (no hc.txt, no flag_chem_evol_save)'
+      stop 1
+    end if
+    multi = racgpu_multi_create(c_string(trim(chemsol_params%chem_files_dir) // trim(chemsol_params%filename_chemical_network)), &
+                                int(ndev, c_int), c_null_ptr)
+    if (.not. c_associated(multi)) then
+      write(*, '(A)') 'racgpu_multi_create: ' // trim(racgpu_multi_error_string())
+      stop 1
+    end if
+    rc = racgpu_multi_calc_cells(multi, p, int(nlocal_iter, c_int32_t), int(ncell, c_int64_t), c_loc(cells), c_loc(y), c_loc(t_final), &
+                                 c_loc(quality), c_loc(stats), c_loc(cell_out), c_null_ptr)
+    if (rc /= 0) then
+      write(*, '(A)') 'racgpu_multi_calc_cells: ' // trim(racgpu_multi_error_string())
+      stop 1
+    end if
+    call racgpu_multi_destroy(multi)
+    write(*, '(A, I3, A)') 'Cells dealt over ', ndev, ' device(s), results gathered with one RCCL all-gather'
+  else if (evolT) then
+    if (nlocal_iter > 1) then
+      write(*, '(A)') 'racgpu_host: with hc.txt (T evolving) nlocal_iter must be 1'
+      stop 1
+    end if
+    rc = racgpu_evolT_solve_batch(net, p, int(ncell, c_int64_t), c_loc(cells), c_loc(hc), c_loc(y), c_null_ptr, c_null_ptr, c_loc(t_final), &
+                                  c_loc(quality), c_loc(stats), prec, ptouts, c_loc(cell_out), 0_c_int, RACGPU_MEM_HOST)
+  else if (nlocal_iter > 1) then
     if (chemsol_params%flag_chem_evol_save) then
       write(*, '(A)') 'racgpu_host: flag_chem_evol_save needs nlocal_iter = 1 (the reference overwrites the file in every local iteration)'
       stop 1
@@ -146,7 +218,7 @@ program racgpu_host
     write(*, '(A)') 'racgpu solve: ' // trim(racgpu_error_string())
     stop 1
   end if
-  write(*, '(A, I8, A, F10.2, A, I12)') 'Solved ', ncell, ' cells; kernel ', racgpu_last_kernel_ms(net), ' ms; total steps ', sum(stats(1, :))
+  if (ndev < 1) write(*, '(A, I8, A, F10.2, A, I12)') 'Solved ', ncell, ' cells; kernel ', racgpu_last_kernel_ms(net), ' ms; total steps ', sum(stats(1, :))
 
   zeros20 = 0D0
   inquire(iolength=reclen) y(:, 1), zeros20
@@ -156,12 +228,12 @@ program racgpu_host
   end do
   close(fu)
   open(newunit=fu, file=trim(prefix) // '.dat', status='replace')
-  write(fmt, '("(", I4, "A14)")') nS + 6
+  write(fmt, '("(", I4, "A14)")') nS + 7
   write(fu, fmt) '  t_final     ', '  quality     ', '  NST         ', '  local_iter  ', '  R_H2_form   ', '  n_mol_grain ', &
-                 (adjustr(names(i) // '  '), i = 1, nS)
-  write(fmt, '("(ES14.5E3, 3I14, ", I4, "ES14.5E3)")') nS + 2
+                 '  Tgas        ', (adjustr(names(i) // '  '), i = 1, nS)
+  write(fmt, '("(ES14.5E3, 3I14, ", I4, "ES14.5E3)")') nS + 3
   do i = 1, ncell
-    write(fu, fmt) t_final(i), quality(i), int(stats(1, i)), int(stats(18, i)), cell_out(1, i), cell_out(2, i), y(:, i)
+    write(fu, fmt) t_final(i), quality(i), int(stats(1, i)), int(stats(18, i)), cell_out(1, i), cell_out(2, i), cell_out(4, i), y(:, i)
   end do
   close(fu)
   if (chemsol_params%flag_chem_evol_save) then

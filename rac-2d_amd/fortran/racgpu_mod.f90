@@ -18,9 +18,51 @@ module racgpu
             racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_column_sweep, racgpu_set_co_shielding_table, racgpu_rectify_abundances, &
             racgpu_set_cost_hints, racgpu_set_team_threshold, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
   public :: racgpu_error_string, chemsol_to_c, c_string
+  ! gas temperature co-evolving with the chemistry (evolT) and the single-process multi-GPU entry points
+  public :: RACGPU_NHC, racgpu_hc_config_t, type_heating_cooling_config, heating_cooling_config, heating_cooling_configure_read, &
+            heating_cooling_to_c, racgpu_hc_config_default, racgpu_heating_cooling_load, racgpu_evolT_solve_batch
+  public :: racgpu_multi_create, racgpu_multi_destroy, racgpu_multi_calc_cells, racgpu_multi_error_string
 
   integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 20, RACGPU_NOUT = 5, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
   integer, parameter :: RACGPU_F_RECTIFY = 1
+  integer, parameter :: RACGPU_NHC = 28 ! per-cell heating/cooling record (include/racgpu.h, RACGPU_H_*)
+
+  ! struct racgpu_hc_config (include/racgpu.h)
+  type, bind(c) :: racgpu_hc_config_t
+    real(c_double) :: heating_eff_chem, heating_eff_H2form, heating_eff_phd_H2, heating_eff_phd_H2O, heating_eff_phd_OH, &
+                      cooling_gg_coeff, base_alpha
+    integer(c_int32_t) :: use_chemicalheatingcooling, use_Xray_heating, use_phdheating_H2, use_phdheating_H2OOH, &
+                          use_mygasgraincooling, may_switch_T
+  end type racgpu_hc_config_t
+
+  ! The reference's &heating_cooling_configure namelist variable (src/heating_cooling.f90:16-38, 53-54): same component names and
+  ! defaults, so that an existing configure file is accepted verbatim.  Branches this engine does not implement are refused.
+  type :: type_heating_cooling_config
+    logical :: use_analytical_CII_OI = .true.
+    logical :: use_mygasgraincooling = .true.
+    logical :: use_chemicalheatingcooling = .true.
+    logical :: use_Xray_heating = .true.
+    logical :: use_phdheating_H2 = .true.
+    logical :: use_phdheating_H2OOH = .true.
+    logical :: dust_gas_linear_couple = .false.
+    integer :: solve_method = 1
+    double precision :: heating_eff_chem = 1D0
+    double precision :: heating_eff_H2form = 0.1D0
+    double precision :: heating_eff_phd_H2 = 1D0
+    double precision :: heating_eff_phd_H2O = 0.1D0
+    double precision :: heating_eff_phd_OH = 0.1D0
+    double precision :: heating_Xray_en = 18.7D0
+    double precision :: cooling_gg_coeff = 0.3D0
+    character(len=128) :: dir_transition_rates = './transitions/'
+    character(len=128) :: filename_CII = 'C+.dat'
+    character(len=128) :: filename_NII = 'N+.dat'
+    character(len=128) :: filename_OI = 'Oatom.dat'
+    character(len=128) :: filename_FeII = 'Fe+.dat'
+    character(len=128) :: filename_SiII = 'Si+.dat'
+    logical :: IonCoolingWithLut = .true.
+  end type type_heating_cooling_config
+  type(type_heating_cooling_config), save :: heating_cooling_config
+  namelist /heating_cooling_configure/ heating_cooling_config
 
   ! struct racgpu_params (include/racgpu.h)
   type, bind(c) :: racgpu_params_t
@@ -232,6 +274,56 @@ module racgpu
       type(c_ptr), value :: h
       real(c_double) :: ms
     end function
+    subroutine racgpu_hc_config_default(c) bind(c, name='racgpu_hc_config_default')
+      import :: racgpu_hc_config_t
+      type(racgpu_hc_config_t), intent(out) :: c
+    end subroutine
+    ! heating_cooling_prepare + the reaction heats: enthalpy file, Neufeld tables (compiled into the reference; here a data file), ion LUTs
+    function racgpu_heating_cooling_load(h, c, enthalpy_file, neufeld_tables, nii_lut, siii_lut, feii_lut) &
+        bind(c, name='racgpu_heating_cooling_load') result(rc)
+      import :: c_ptr, racgpu_hc_config_t, c_char, c_int
+      type(c_ptr), value :: h
+      type(racgpu_hc_config_t), intent(in) :: c
+      character(kind=c_char), dimension(*), intent(in) :: enthalpy_file, neufeld_tables, nii_lut, siii_lut, feii_lut
+      integer(c_int) :: rc
+    end function
+    ! racgpu_evol_solve_batch with the gas temperature co-evolving (chemsol_params%evolT): hc = [RACGPU_NHC, ncell]
+    function racgpu_evolT_solve_batch(h, p, ncell, cells, hc, y, t0, tol_j, t_final, quality, stats, record, touts, cell_out, flags, mem) &
+        bind(c, name='racgpu_evolT_solve_batch') result(rc)
+      import :: c_ptr, racgpu_params_t, c_int64_t, c_int
+      type(c_ptr), value :: h
+      type(racgpu_params_t), intent(in) :: p
+      integer(c_int64_t), value :: ncell
+      type(c_ptr), value :: cells, hc, y, t0, tol_j, t_final, quality, stats, record, touts, cell_out
+      integer(c_int), value :: flags, mem
+      integer(c_int) :: rc
+    end function
+    ! one process, ndev GPUs, one RCCL all-gather of the results (include/racgpu.h); devices = c_null_ptr: 0 .. ndev-1
+    function racgpu_multi_create(path, ndev, devices) bind(c, name='racgpu_multi_create') result(m)
+      import :: c_ptr, c_char, c_int
+      character(kind=c_char), dimension(*), intent(in) :: path
+      integer(c_int), value :: ndev
+      type(c_ptr), value :: devices
+      type(c_ptr) :: m
+    end function
+    subroutine racgpu_multi_destroy(m) bind(c, name='racgpu_multi_destroy')
+      import :: c_ptr
+      type(c_ptr), value :: m
+    end subroutine
+    function racgpu_multi_last_error() bind(c, name='racgpu_multi_last_error') result(p)
+      import :: c_ptr
+      type(c_ptr) :: p
+    end function
+    function racgpu_multi_calc_cells(m, p, nlocal_iter, ncell, cells, y, t_final, quality, stats, cell_out, cost) &
+        bind(c, name='racgpu_multi_calc_cells') result(rc)
+      import :: c_ptr, racgpu_params_t, c_int64_t, c_int32_t, c_int
+      type(c_ptr), value :: m
+      type(racgpu_params_t), intent(in) :: p
+      integer(c_int32_t), value :: nlocal_iter
+      integer(c_int64_t), value :: ncell
+      type(c_ptr), value :: cells, y, t_final, quality, stats, cell_out, cost
+      integer(c_int) :: rc
+    end function
   end interface
 
 contains
@@ -261,6 +353,54 @@ contains
     end do
   end function racgpu_error_string
 
+  function racgpu_multi_error_string() result(s)
+    character(len=256) :: s
+    character(kind=c_char), dimension(:), pointer :: p
+    type(c_ptr) :: cp
+    integer :: i
+    s = ''
+    cp = racgpu_multi_last_error()
+    if (.not. c_associated(cp)) return
+    call c_f_pointer(cp, p, [256])
+    do i = 1, 256
+      if (p(i) == c_null_char) exit
+      s(i:i) = p(i)
+    end do
+  end function racgpu_multi_error_string
+
+  ! read &heating_cooling_configure as the reference does (src/configure.f90:29); ios /= 0 when the file has none
+  subroutine heating_cooling_configure_read(funit, ios)
+    integer, intent(in) :: funit
+    integer, intent(out) :: ios
+    read(funit, nml=heating_cooling_configure, iostat=ios)
+  end subroutine heating_cooling_configure_read
+
+  ! namelist values -> the C struct; the branches the engine does not implement are refused, not ignored
+  subroutine heating_cooling_to_c(c, base_alpha, may_switch_T)
+    type(racgpu_hc_config_t), intent(out) :: c
+    double precision, intent(in) :: base_alpha
+    logical, intent(in) :: may_switch_T
+    if ((.not. heating_cooling_config%use_analytical_CII_OI) .or. (.not. heating_cooling_config%IonCoolingWithLut) .or. &
+        heating_cooling_config%dust_gas_linear_couple) then
+      write(*, '(A)') 'racgpu: only use_analytical_CII_OI = IonCoolingWithLut = .true., dust_gas_linear_couple = .false. are implemented'
+      stop 1
+    end if
+    call racgpu_hc_config_default(c)
+    c%heating_eff_chem = heating_cooling_config%heating_eff_chem
+    c%heating_eff_H2form = heating_cooling_config%heating_eff_H2form
+    c%heating_eff_phd_H2 = heating_cooling_config%heating_eff_phd_H2
+    c%heating_eff_phd_H2O = heating_cooling_config%heating_eff_phd_H2O
+    c%heating_eff_phd_OH = heating_cooling_config%heating_eff_phd_OH
+    c%cooling_gg_coeff = heating_cooling_config%cooling_gg_coeff
+    c%base_alpha = base_alpha
+    c%use_chemicalheatingcooling = merge(1, 0, heating_cooling_config%use_chemicalheatingcooling)
+    c%use_Xray_heating = merge(1, 0, heating_cooling_config%use_Xray_heating)
+    c%use_phdheating_H2 = merge(1, 0, heating_cooling_config%use_phdheating_H2)
+    c%use_phdheating_H2OOH = merge(1, 0, heating_cooling_config%use_phdheating_H2OOH)
+    c%use_mygasgraincooling = merge(1, 0, heating_cooling_config%use_mygasgraincooling)
+    c%may_switch_T = merge(1, 0, may_switch_T)
+  end subroutine heating_cooling_to_c
+
   ! read &chemistry_configure exactly as the reference does (src/configure.f90:28)
   subroutine chemistry_configure_read(funit, ios)
     integer, intent(in) :: funit
@@ -274,10 +414,6 @@ contains
     ! switches of the reference this engine does not implement are refused, not ignored (DESIGN.md section 0)
     if (chemsol_params%update_gH_params_realtime) then
       write(*, '(A)') 'racgpu: chemsol_params%update_gH_params_realtime = .true. is not implemented'
-      stop 1
-    end if
-    if (chemsol_params%evolT) then
-      write(*, '(A)') 'racgpu: chemsol_params%evolT = .true. (gas temperature co-evolution) is not implemented'
       stop 1
     end if
     call racgpu_params_default(p)

@@ -68,13 +68,13 @@ def solve_sharded(solve_local, cells, y, dist=None, device=None, cost=None):
                 stats=np.rint(full[:, nS + 2:]).astype(np.int64))
 
 
-def solve_by_layers(solve, cells, y, layer, update=None):
+def solve_by_layers(solve, cells, y, layer, update=None, update_surface=True):
     """The caller's sweep in dependency order: the reference solves a cell only after the cells above it, because the
     self-shielding factors in its record are integrals over what those cells ended with (update_params_above_alt, reference
     src/disk.f90:1823-1883; the list of cells that may be solved next is kept by update_calculating_cells, :1937).  Here every
-    LAYER is one batch: layer 0 (the surface) first, then for each further layer ``update(k, idx, cells, y_done, done)`` may
-    rewrite the records ``cells[idx]`` of that layer from the end states ``y_done`` of all cells solved so far (``done``: their
-    indices) before the layer is solved as one batch.  Layers of a few hundred cells do not fill the GPU with one wave per
+    LAYER is one batch: layer 0 (the surface) first; before a layer is solved as one batch ``update(k, idx, cells, y_done, done)``
+    may rewrite its records ``cells[idx]`` from the end states ``y_done`` of all cells solved so far (``done``: their indices; empty
+    for the surface layer, which is skipped with ``update_surface=False``).  Layers of a few hundred cells do not fill the GPU with one wave per
     cell; the engine hands them to four-wave teams by itself.
 
     solve(cells_block, y_block) -> dict(y, t_final, quality, stats) (e.g. a closure over Network.evol_solve_batch);
@@ -90,7 +90,8 @@ def solve_by_layers(solve, cells, y, layer, update=None):
     done = np.zeros(0, dtype=np.int64)
     for k in np.unique(layer):
         idx = np.nonzero(layer == k)[0]
-        if update is not None and done.size:
+        # (the surface layer too, with nothing above it: update_params_above_alt runs for every cell, column densities 0 there)
+        if update is not None and (done.size or update_surface):
             update(int(k), idx, cells, y_out, done)
         res = solve(np.ascontiguousarray(cells[idx]), np.ascontiguousarray(y_out[idx]))
         y_out[idx] = res["y"]

@@ -30,9 +30,9 @@ def test_fortran_host_matches_reference(tmp_path, racgpu):
         floor = major_relerr(g["yend_ulp"][c][:nS], ref)
         assert major_relerr(rec[c, :nS], ref) <= max(1e-4, 3 * floor)
     rows = open(tmp_path / "out.dat").read().splitlines()
-    assert len(rows) == 3 and len(rows[0]) == 14 * (nS + 6)
-    hdr = [rows[0][14 * k:14 * (k + 1)].strip() for k in range(nS + 6)]
-    assert hdr[6:] == list(g["species"])
+    assert len(rows) == 3 and len(rows[0]) == 14 * (nS + 7)
+    hdr = [rows[0][14 * k:14 * (k + 1)].strip() for k in range(nS + 7)]
+    assert hdr[6] == "Tgas" and hdr[7:] == list(g["species"])
     # restart from the .bin just written (the reference's use_backup_chemical_data path), local-iteration loop on: cells
     # that finished with quality 0 stay as they are handed in (t0 = 0 again, so this is a second full run from the end state)
     out2 = subprocess.run([HOST, os.path.join(ROOT, "tests", "fortran_host", "configure_chemistry.dat"), str(tmp_path / "cells.txt"),
@@ -84,3 +84,69 @@ def test_fortran_host_reads_reference_namelist_without_gpu(tmp_path, racgpu):
     out = subprocess.run([HOST, os.path.join(ROOT, "tests", "fortran_host", "configure_chemistry.dat"),
                           str(tmp_path / "cells.txt"), str(tmp_path / "out")], cwd=ROOT, capture_output=True, text=True)
     assert out.returncode == 1 and "no HIP device" in out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_fortran_host_through_the_multi_gpu_entry_point(tmp_path, racgpu):
+    """ndev = 1 on the one-GPU box: the cells go through racgpu_multi_calc_cells (dealing, one host thread per device, the RCCL
+    all-gather of the result rows over a one-rank communicator) and must come back exactly as the single-device call returns them."""
+    if not os.path.exists(HOST):
+        pytest.skip("racgpu_host not built")
+    g = load_golden("rate06_nograin")
+    np.savetxt(tmp_path / "cells.txt", g["cells"][:3], fmt="%.17e")
+    conf = os.path.join(ROOT, "tests", "fortran_host", "configure_chemistry.dat")
+    a = subprocess.run([HOST, conf, str(tmp_path / "cells.txt"), str(tmp_path / "one"), "2"], cwd=ROOT, capture_output=True, text=True)
+    b = subprocess.run([HOST, conf, str(tmp_path / "cells.txt"), str(tmp_path / "multi"), "2", "-", "1"], cwd=ROOT, capture_output=True, text=True)
+    assert a.returncode == 0 and b.returncode == 0, a.stdout + a.stderr + b.stdout + b.stderr
+    assert "one RCCL all-gather" in b.stdout
+    assert (tmp_path / "one.bin").read_bytes() == (tmp_path / "multi.bin").read_bytes()
+    ra, rb = open(tmp_path / "one.dat").read().splitlines(), open(tmp_path / "multi.dat").read().splitlines()
+    assert ra == rb
+
+
+@pytest.mark.gpu
+def test_fortran_host_with_the_gas_temperature_evolving(tmp_path, racgpu):
+    """hc.txt given: chemsol_params%evolT for every cell with en_gain_tot > 0; checked against the reference's own evolT run of the same
+    cells (tests/golden/evolT_grain.npz)."""
+    if not os.path.exists(HOST):
+        pytest.skip("racgpu_host not built")
+    g = load_golden("evolT_grain")
+    sel = [1, 5]
+    np.savetxt(tmp_path / "cells.txt", g["cells"][sel], fmt="%.17e")
+    np.savetxt(tmp_path / "hc.txt", g["hc"][sel], fmt="%.17e")
+    conf = open(os.path.join(ROOT, "tests", "fortran_host", "configure_chemistry.dat")).read()
+    conf = conf.replace("rate06_dipole_reformated_again_withoutgrain.dat", str(g["network_file"]))
+    assert str(g["network_file"]) in conf
+    conf += """&heating_cooling_configure
+  heating_cooling_config%dir_transition_rates    = '%s/'
+  heating_cooling_config%use_analytical_CII_OI   = .true.
+  heating_cooling_config%IonCoolingWithLut       = .true.
+  heating_cooling_config%filename_NII            = 'N+_LUT.bin'
+  heating_cooling_config%filename_SiII           = 'Si+_LUT.bin'
+  heating_cooling_config%filename_FeII           = 'Fe+_LUT.bin'
+  heating_cooling_config%solve_method            = 2
+  heating_cooling_config%use_mygasgraincooling      = .true.
+  heating_cooling_config%use_chemicalheatingcooling = .true.
+  heating_cooling_config%use_Xray_heating           = .true.
+  heating_cooling_config%heating_Xray_en            = 0.0D0
+  heating_cooling_config%heating_eff_chem           = 0.3D0
+  heating_cooling_config%heating_eff_H2form         = 0.5D0
+  heating_cooling_config%heating_eff_phd_H2         = 1D0
+  heating_cooling_config%heating_eff_phd_H2O        = 0.5D0
+  heating_cooling_config%heating_eff_phd_OH         = 0.5D0
+  heating_cooling_config%cooling_gg_coeff           = 1D0
+/
+""" % DATA
+    (tmp_path / "conf.dat").write_text(conf)
+    out = subprocess.run([HOST, str(tmp_path / "conf.dat"), str(tmp_path / "cells.txt"), str(tmp_path / "out"), "1", "-", "0", str(tmp_path / "hc.txt")],
+                         cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    nS = len(g["species"])
+    rec = np.fromfile(tmp_path / "out.bin", dtype=np.float64).reshape(2, nS + 20)
+    rows = open(tmp_path / "out.dat").read().splitlines()
+    for k, c in enumerate(sel):
+        ref, twin = g["yend"][c], g["yend_ulp"][c]
+        floor = max(major_relerr(twin[:nS], ref[:nS]), abs(twin[nS] - ref[nS]) / ref[nS])
+        assert major_relerr(rec[k, :nS], ref[:nS]) <= max(1e-4, 3 * floor)
+        T = float(rows[1 + k][14 * 6:14 * 7])
+        assert abs(T - ref[nS]) <= max(1e-4, 3 * floor) * ref[nS] + 5e-6 * ref[nS]  # (ES14.5E3: six digits)
