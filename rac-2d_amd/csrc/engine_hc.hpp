@@ -72,6 +72,8 @@ RG_DEV double hc_lut(const RG_GLOBAL IonLut &L, double x, double y) { // spline2
   const double C = (A * A * A - A) * (dx * dx) / 6.0, D = (B * B * B - B) * (dx * dx) / 6.0;
   return A * v0 + B * v1 + C * 0.0 + D * 0.0;
 }
+static __shared__ volatile double g_hc_terms[HC_NTERMS];
+#define HC_BLOCK() asm volatile("" ::: "memory")
 RG_DEV double hc_tau2beta(double tau) { // tau2beta (src/sub_trivials.f90:1064-1085), factor 3
   if (tau <= 1e-4) return 1.0;
   const double tmp = 3.0 * tau;
@@ -81,22 +83,44 @@ RG_DEV double hc_tau2beta(double tau) { // tau2beta (src/sub_trivials.f90:1064-1
 // dT/dt [K yr^-1] of one cell at (y, T).  cell: the RACGPU_NPAR record, hr: the RACGPU_NHC record, rates: the cell's rate
 // coefficients AT T (chem_cal_rates has just run for it), rh2: R_H2_form_rate_coeff of that call.  terms (nullable): where
 // lane 0 stores the 29 values of HC_* [erg s^-1 cm^-3].
-RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const double *__restrict__ cell, const double *__restrict__ hr,
+#ifndef RG_HC_NOINLINE
+#define RG_HC_NOINLINE 1 // a real call: inlined at its twelve call sites the terms' registers add to the integrator's (256 VGPRs + AGPR spills, one wave per SIMD)
+#endif
+#if RG_HC_NOINLINE
+__device__ __attribute__((noinline))
+#else
+RG_DEV
+#endif
+double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const double *__restrict__ cell, const double *__restrict__ hr,
                                   const double *y, double T, const double *__restrict__ rates, double rh2, int lane, double *terms = nullptr) {
   using namespace hcc;
   const RG_GLOBAL HcConfig &cfg = H.cfg;
   auto ab = [&](int i) { return i >= 0 ? y[i] : 0.0; };
-  const double X_H2 = ab(H.i_H2), X_HI = ab(H.i_HI), X_CI = ab(H.i_CI), X_CII = ab(H.i_CII), X_OI = ab(H.i_OI), X_NII = ab(H.i_NII),
-               X_FeII = ab(H.i_FeII), X_SiII = ab(H.i_SiII), X_CO = ab(H.i_CO), X_H2O = ab(H.i_H2O), X_OH = ab(H.i_OH), X_E = ab(H.i_E),
-               X_Hplus = ab(H.i_Hplus), X_Heplus = ab(H.i_Heplus), X_gH = ab(H.i_gH);
-  const double n_gas = cell[2], Tdust = cell[1];
+  // (abundances and record fields are read where they are used: see HC_BLOCK)
+#define X_H2 ab(H.i_H2)
+#define X_HI ab(H.i_HI)
+#define X_CI ab(H.i_CI)
+#define X_CII ab(H.i_CII)
+#define X_OI ab(H.i_OI)
+#define X_NII ab(H.i_NII)
+#define X_FeII ab(H.i_FeII)
+#define X_SiII ab(H.i_SiII)
+#define X_CO ab(H.i_CO)
+#define X_H2O ab(H.i_H2O)
+#define X_OH ab(H.i_OH)
+#define X_E ab(H.i_E)
+#define X_Hplus ab(H.i_Hplus)
+#define X_Heplus ab(H.i_Heplus)
+#define X_gH ab(H.i_gH)
+#define n_gas cell[2]
+#define Tdust cell[1]
   // get_H2_form_rate (H2_form_use_moeq = .false.)
   const double R_H2_form = H.i_gH >= 0 ? rh2 * X_gH * X_gH * n_gas : rh2 * X_HI * n_gas;
   // get_alpha_viscosity_alt: ion charge = sum of charge * y over the positively charged species with y >= 1e-30
   double q = 0.0;
   for (int i = lane; i < N.nS; i += 64) { const int ch = gptr(N.s_charge)[i]; const double yi = y[i]; if (yi >= 1e-30 && ch > 0) q += (double)ch * yi; }
   const double ion_charge = wave_sum(q);
-  const double omega_K = hr[H_OMEGA_K];
+#define omega_K hr[H_OMEGA_K]
   const double ambipolar_f = n_gas * ion_charge * beta_ion_neutral / omega_K;
   double alpha_visc = 0.0;
   if (ambipolar_f > 1e-20) {
@@ -105,12 +129,22 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
   }
   alpha_visc = cfg.base_alpha * alpha_visc;
 
-  const double G0_ISM = cell[14], G0_star = cell[15], Av_ISM = cell[12], Av_star = cell[13], Ncol_ISM = cell[11], Ncol_star = hr[H_NCOL_STAR];
+#define G0_ISM cell[14]
+#define G0_star cell[15]
+#define Av_ISM cell[12]
+#define Av_star cell[13]
+#define Ncol_ISM cell[11]
+#define Ncol_star hr[H_NCOL_STAR]
   const double chi_all = G0_ISM * exp(-cst::UVext2Av * Av_ISM) + G0_star * exp(-cst::UVext2Av * Av_star);
   const double chi_H2 = G0_ISM * exp(-cst::UVext2Av * Av_ISM) * cell[19] + cell[16] * cell[23];
-  const double PAH = hr[H_PAH], coh = hr[H_COHERENT], dv_turb = hr[H_DV_TURB];
-  double r[HC_NTERMS];
+#define PAH hr[H_PAH]
+#define coh hr[H_COHERENT]
+#define dv_turb hr[H_DV_TURB]
+  // the terms go to LDS one by one (every lane writes the same value), and every block below starts from memory again (HC_BLOCK): kept
+  // in registers with their inputs they make this scalar function the register-hungriest of the kernel (248 VGPRs)
+  volatile double *r = g_hc_terms;
   // ---- heating -------------------------------------------------------------------------------------------------------------
+  HC_BLOCK();
   { // photoelectric, small grains (Bakes & Tielens 1994 as the reference codes it)
     double v = 0.0;
     if (!(X_E <= 0.0 || T <= 0.0)) {
@@ -121,17 +155,25 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_H_PE] = v;
   }
+  HC_BLOCK();
   r[HC_H_H2FORM] = 2.4e-12 * R_H2_form * cfg.heating_eff_H2form;
+  HC_BLOCK();
   r[HC_H_CR] = 1.5e-11 * cell[9] * n_gas * exp(-Ncol_ISM / cst::CRattenN);
+  HC_BLOCK();
   {
     double v = 0.0;
     if (T > 0.0) { const double g10 = 5.4e-13 * sqrt(T); v = (n_gas * X_H2) * chi_H2 * 9.4e-22 / (1.0 + (1.9e-6 + chi_H2 * 4.7e-10) / (n_gas * g10)); }
     r[HC_H_VIBH2] = v;
   }
+  HC_BLOCK();
   r[HC_H_CI] = 2.2e-22 * X_CI * n_gas * chi_all;
+  HC_BLOCK();
   r[HC_H_PHD_H2] = cfg.use_phdheating_H2 ? 4e-14 * (n_gas * X_H2) * 3.4e-10 * chi_H2 * cfg.heating_eff_phd_H2 : 0.0;
+  HC_BLOCK();
   r[HC_H_PHD_H2O] = cfg.use_phdheating_H2OOH ? (8.07e-12 * cfg.heating_eff_phd_H2O) * (n_gas * X_H2O) * LyA_H2O * (cell[18] * cell[25]) : 0.0;
+  HC_BLOCK();
   r[HC_H_PHD_OH] = cfg.use_phdheating_H2OOH ? (9.19e-12 * cfg.heating_eff_phd_OH) * (n_gas * X_OH) * LyA_OH * (cell[18] * cell[26]) : 0.0;
+  HC_BLOCK();
   { // X-ray heating per ion pair (Glassgold et al. 2012)
     double v = 0.0;
     if (cfg.use_Xray_heating) {
@@ -156,6 +198,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_H_XRAY] = v;
   }
+  HC_BLOCK();
   {
     double v = 0.0;
     if (T > 0.0) {
@@ -164,6 +207,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_H_VISC] = v;
   }
+  HC_BLOCK();
   { // chemical heating: sum over the reactions with a heat, k * y_a * y_b * heat
     double v = 0.0;
     if (cfg.use_chemicalheatingcooling && T > 0.0) {
@@ -177,6 +221,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     r[HC_H_CHEM] = v;
   }
   // ---- cooling -------------------------------------------------------------------------------------------------------------
+  HC_BLOCK();
   {
     double v = 0.0;
     if (!(X_E <= 0.0 || T <= 0.0 || PAH <= 0.0)) {
@@ -188,6 +233,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_PE] = v;
   }
+  HC_BLOCK();
   {
     double v = 0.0;
     if (T > 0.0) {
@@ -196,6 +242,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_VIBH2] = v;
   }
+  HC_BLOCK();
   { // gas-grain collisions
     double v = 0.0;
     if (T > 0.0) {
@@ -216,7 +263,8 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_GG] = v;
   }
-  const double Ncool = fmin(fmin(Ncol_ISM, Ncol_star), n_gas * coh);
+#define Ncool fmin(fmin(Ncol_ISM, Ncol_star), n_gas * coh)
+  HC_BLOCK();
   { // [OI] 63, 146 um and 6300 A, analytic
     double v = 0.0;
     if (T > 0.0) {
@@ -234,6 +282,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_OI] = v;
   }
+  HC_BLOCK();
   {
     double v = 0.0;
     if (T > 0.0) {
@@ -242,8 +291,9 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_CII] = v;
   }
-  const double n_H2 = n_gas * X_H2;
+#define n_H2 (n_gas * X_H2)
   const double ln10 = log(10.0);
+  HC_BLOCK();
   { // Neufeld H2O, rotational and vibrational
     double vr = 0.0, vv = 0.0;
     if (!(X_H2O <= 0.0 || X_H2 <= 0.0 || T <= 0.0)) {
@@ -289,6 +339,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_H2O_ROT] = vr; r[HC_C_H2O_VIB] = vv;
   }
+  HC_BLOCK();
   { // Neufeld CO
     double vr = 0.0, vv = 0.0;
     if (!(X_CO <= 0.0 || X_H2 <= 0.0 || T <= 0.0)) {
@@ -325,6 +376,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_CO_ROT] = vr; r[HC_C_CO_VIB] = vv;
   }
+  HC_BLOCK();
   { // Neufeld H2 rotational
     double v = 0.0;
     if (!(T <= 0.0 || X_H2 <= 0.0)) {
@@ -341,7 +393,9 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_H2_ROT] = v;
   }
+  HC_BLOCK();
   r[HC_C_LYA] = T > 0.0 ? 7.3e-19 * (n_gas * n_gas) * X_HI * X_E * exp(-118400.0 / T) : 0.0;
+  HC_BLOCK();
   {
     double v = 0.0;
     if (T > 0.0) {
@@ -350,7 +404,9 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_FB] = v;
   }
+  HC_BLOCK();
   r[HC_C_FF] = T > 0.0 ? 1.4e-27 * 1.0 * sqrt(T) * 1.3 * (n_gas * X_E) * (n_gas * (X_Hplus + X_Heplus)) : 0.0;
+  HC_BLOCK();
   {
     auto ion = [&](double X, const RG_GLOBAL IonLut &L) {
       if (X <= 1e-15 || X_E <= 0.0 || n_gas <= 0.0 || T <= 0.0) return 0.0;
@@ -358,6 +414,7 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     };
     r[HC_C_NII] = ion(X_NII, H.nii); r[HC_C_SIII] = ion(X_SiII, H.siii); r[HC_C_FEII] = ion(X_FeII, H.feii);
   }
+  HC_BLOCK();
   { // OH rotational (Hollenbach & McKee 1989; Gorti & Hollenbach 2004)
     double v = 0.0;
     if (!(X_OH <= 0.0 || X_H2 < 0.0 || X_H2 >= 1.0 || T <= 0.0)) {
@@ -375,14 +432,46 @@ RG_DEV double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, con
     }
     r[HC_C_OH_ROT] = v;
   }
+  HC_BLOCK();
   // heating_minus_cooling, in the reference's order of summation
   double net = r[HC_H_PE] + r[HC_H_H2FORM] + r[HC_H_CR] + r[HC_H_VIBH2] + r[HC_H_CI] + r[HC_H_PHD_H2] + r[HC_H_PHD_H2O] + r[HC_H_PHD_OH] + r[HC_H_XRAY] +
                r[HC_H_VISC] + r[HC_H_CHEM];
   net = net - r[HC_C_PE] - r[HC_C_VIBH2] - r[HC_C_GG] - r[HC_C_OI] - r[HC_C_CII] - r[HC_C_H2O_ROT] - r[HC_C_H2O_VIB] - r[HC_C_CO_ROT] - r[HC_C_CO_VIB] -
         r[HC_C_H2_ROT] - r[HC_C_LYA] - r[HC_C_FB] - r[HC_C_FF] - r[HC_C_NII] - r[HC_C_SIII] - r[HC_C_FEII] - r[HC_C_OH_ROT];
+  HC_BLOCK();
   r[HC_NET] = net;
   if (terms && lane == 0) for (int k = 0; k < HC_NTERMS; ++k) terms[k] = r[k];
+  HC_BLOCK();
   return uniform_d(net * cst::SecPerYear / (n_gas * cst::kB));
+#undef X_H2
+#undef X_HI
+#undef X_CI
+#undef X_CII
+#undef X_OI
+#undef X_NII
+#undef X_FeII
+#undef X_SiII
+#undef X_CO
+#undef X_H2O
+#undef X_OH
+#undef X_E
+#undef X_Hplus
+#undef X_Heplus
+#undef X_gH
+#undef n_gas
+#undef Tdust
+#undef G0_ISM
+#undef G0_star
+#undef Av_ISM
+#undef Av_star
+#undef Ncol_ISM
+#undef Ncol_star
+#undef PAH
+#undef coh
+#undef dv_turb
+#undef omega_K
+#undef Ncool
+#undef n_H2
 }
 
 } // namespace racgpu

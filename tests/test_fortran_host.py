@@ -118,7 +118,7 @@ def test_fortran_host_with_the_gas_temperature_evolving(tmp_path, racgpu):
     conf = conf.replace("rate06_dipole_reformated_again_withoutgrain.dat", str(g["network_file"]))
     assert str(g["network_file"]) in conf
     conf += """&heating_cooling_configure
-  heating_cooling_config%dir_transition_rates    = '%s/'
+  heating_cooling_config%dir_transition_rates    = 'DATADIR/'
   heating_cooling_config%use_analytical_CII_OI   = .true.
   heating_cooling_config%IonCoolingWithLut       = .true.
   heating_cooling_config%filename_NII            = 'N+_LUT.bin'
@@ -136,7 +136,7 @@ def test_fortran_host_with_the_gas_temperature_evolving(tmp_path, racgpu):
   heating_cooling_config%heating_eff_phd_OH         = 0.5D0
   heating_cooling_config%cooling_gg_coeff           = 1D0
 /
-""" % DATA
+""".replace("DATADIR", DATA)
     (tmp_path / "conf.dat").write_text(conf)
     out = subprocess.run([HOST, str(tmp_path / "conf.dat"), str(tmp_path / "cells.txt"), str(tmp_path / "out"), "1", "-", "0", str(tmp_path / "hc.txt")],
                          cwd=ROOT, capture_output=True, text=True)

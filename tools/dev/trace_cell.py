@@ -13,6 +13,7 @@ if which == "gpu":
     os.environ["RACGPU_DEBUG_TRACE"] = sys.argv[4]
     R = importlib.import_module("rac-2d_amd")
     net = R.Network(netf)
+    net.set_team_threshold(-1.0)  # one wave, no hand-over: the trace belongs to the wave that starts the cell
     y0 = net.load_initial_abundances(inif)
     p = R.default_params(); p.RTOL = rtol; p.max_runtime_allowed = 0.0
     out = net.evol_solve_batch(p, cell, net.init_abundances(y0, cell))
