@@ -67,6 +67,16 @@ def algorithmic_bytes(nS, nR, nnzJ, nzl, nzu, nst, nfe, nje, nlu, qsum):
                   + 4.0 * (qsum + nst) * neq + 6.0 * nst * neq)
 
 
+def algorithmic_bytes_evolT(nS, nR, nnzJ, nzl, nzu, nst, nfe, nje, nlu, qsum):
+    """The same with the gas temperature co-evolving: every f(y) also WRITES the rate vector it recomputes at the
+    iterate's T (+nR per f); a Jacobian costs two more f(y, T + dT) for the T column (+2(nR + NEQ)) and writes the T column of P;
+    a factorisation rescales/reads the T column and writes z = A^-1 b (+3 NEQ); a solve reads z (+NEQ)."""
+    neq = nS + 1
+    nnzlu = nzl + nzu + neq
+    return 8.0 * (nfe * (nnzlu + 2 * neq) + nfe * (2 * nR + 2 * neq) + nlu * (nnzJ + nnzlu + 3 * neq) + nje * (3 * nR + nnzJ + 4 * neq)
+                  + 4.0 * (qsum + nst) * neq + 6.0 * nst * neq)
+
+
 def _read_sections(fn):
     d, cur = {}, None
     for line in open(fn):
@@ -106,7 +116,7 @@ def cpu_model():
     return "unknown"
 
 
-def run_reference(sample, network, initial, params, rtol=None):
+def run_reference(sample, network, initial, params, rtol=None, hc=None):
     """oracle/_ref/ref_driver on the rows of `sample`, one process per host core; returns (list of section dicts, seconds, cores)
     or (None, 0, cores) when the binary is absent or fails.  Every dict also carries "errcodes": the cell's error returns by ISTATE
     code (-1, -4, -5, other)."""
@@ -125,13 +135,17 @@ def run_reference(sample, network, initial, params, rtol=None):
             os.makedirs(d)
             dirs.append((w, d, len(part)))
             np.savetxt(os.path.join(d, "cells.txt"), part, fmt="%.17e")
+            extra = ""
+            if hc is not None:  # gas temperature co-evolving: the cells' heating/cooling records; tables and enthalpies from data/
+                np.savetxt(os.path.join(d, "hc.txt"), hc[w::cores], fmt="%.17e")
+                extra = " evolT=1\n hc_file='%s'\n enthalpy='Species_enthalpy.dat'\n transitions_dir='%s/'\n" % (os.path.join(d, "hc.txt"), DATA)
             with open(os.path.join(d, "run.nml"), "w") as f:
                 f.write("&ref_run\n chem_dir='%s/'\n network='%s'\n initial='%s'\n out_dir='%s'\n cell_file='%s'\n ncell=%d\n"
                         " rtol=%.17e\n atol=%.17e\n dt_first_step=%.17e\n ratio_tstep=%.17e\n t_max=%.17e\n mxstep=%d\n"
-                        " steps_reset=%d\n dump_jac=0\n solve=1\n/\n" % (
+                        " steps_reset=%d\n dump_jac=0\n solve=1\n" % (
                             DATA, network, initial, d, os.path.join(d, "cells.txt"), len(part), rtol or params.RTOL, params.ATOL,
                             params.dt_first_step, params.ratio_tstep, params.t_max, params.mxstep_per_interval,
-                            params.steps_reset_solver))
+                            params.steps_reset_solver) + extra + "/\n")
             procs.append(subprocess.Popen([driver, os.path.join(d, "run.nml")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
         ok = all(p.wait() == 0 for p in procs)
         dt = time.perf_counter() - t0
@@ -146,13 +160,14 @@ def run_reference(sample, network, initial, params, rtol=None):
     return [ref[k] for k in range(len(sample))], dt, cores
 
 
-def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS, tight=None):
+def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS, tight=None, hc=None):
     """The reference's own Fortran path (oracle/_ref/ref_driver, built from the unmodified sources in the build container)
     on a bounded sample of the same cells, one process per host core.  Returns (cpu_baseline, parity).  Falls back to the
     C restatement (kind "port", single thread).  Baseline and checker only: nothing here is on the product path."""
     sample = cells[sample_idx]
     nsample = len(sample)
-    ref, dt, cores = run_reference(sample, network, initial, params)
+    hcs = None if hc is None else hc[sample_idx]
+    ref, dt, cores = run_reference(sample, network, initial, params, hc=hcs)
     if ref is not None:
         steps = float(np.sum(gpu["nst"][sample_idx]))
         base = {"value": steps / dt, "unit": "cell-steps/s", "cores": cores, "kind": "reference", "cpu_model": cpu_model(),
@@ -161,12 +176,23 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                           % (nsample, max(1, len(cells) // nsample), min(cores, nsample), dt)}
         # The reference's own rounding-noise floor on THESE cells: the same binary on the same cells with n_gas moved by one ulp
         # (the recipe of tests/golden/make_golden.py).  A cell's floor = how far that moves the reference's own end state.
-        twin_cells = sample.copy()
-        twin_cells[:, 2] = np.nextafter(twin_cells[:, 2], np.inf)
-        twin_cells[:, 5] = twin_cells[:, 2] * twin_cells[:, 6]
-        twin, _, _ = run_reference(twin_cells, network, initial, params)
+        # Three twins (n_gas up and down by one ulp, Tgas up by one ulp): one sample of a chaotic quantity underestimates it.
+        twins = []
+        for col, up in ((2, True), (2, False), (0, True)):
+            twin_cells = sample.copy()
+            twin_cells[:, col] = np.nextafter(twin_cells[:, col], np.inf if up else 0.0)
+            twin_cells[:, 5] = twin_cells[:, 2] * twin_cells[:, 6]
+            thc = None
+            if hcs is not None:
+                thc = hcs.copy(); thc[:, 16] = twin_cells[:, 5]  # (n_dusts of the single dust component = ndust_tot)
+            tw, _, _ = run_reference(twin_cells, network, initial, params, hc=thc)
+            if tw is not None:
+                twins.append(tw)
+        twin = twins[0] if twins else None
 
-        def worst(yg, yr):
+        def worst(yg, yr):  # (with T evolving the last entry of the reference's y is the temperature: it counts like a major species)
+            n = nS + 1 if hcs is not None else nS
+            yg, yr = np.asarray(yg)[:n], np.asarray(yr)[:n]
             m = yr >= 1e-6
             e = np.zeros_like(yr)
             e[m] = np.abs(yg[m] - yr[m]) / yr[m]
@@ -177,10 +203,11 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
         ne_ref_twin_eq = 0
         for k in range(nsample):
             r = ref[k]
-            yr = r["yend"][:nS]
-            e, sp = worst(gpu["y"][sample_idx[k]], yr)
+            yr = r["yend"]
+            yg = gpu["y"][sample_idx[k]] if hcs is None else np.r_[gpu["y"][sample_idx[k]], gpu["tgas"][sample_idx[k]]]
+            e, sp = worst(yg, yr)
             errs.append(e); spec.append(sp)
-            floors.append(worst(twin[k]["yend"][:nS], yr)[0] if twin is not None else 0.0)
+            floors.append(max([worst(tw[k]["yend"], yr)[0] for tw in twins]) if twins else 0.0)
             tf_eq += int(r["scalars"][0] == gpu["t_final"][sample_idx[k]])
             q_eq += int(int(r["scalars"][1]) == int(gpu["quality"][sample_idx[k]]))
             ne_eq += int(int(r["scalars"][2]) == int(gpu["nerr"][sample_idx[k]]))
@@ -198,7 +225,8 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
         parity = {"against": "reference Fortran/DLSODES end states of the cpu_baseline sample, same RTOL (%g); species with X >= 1e-6" % params.RTOL,
                   "cells": nsample, "max_rel_err": float(errs.max()), "median_rel_err": float(np.median(errs)),
                   "p90_rel_err": float(np.percentile(errs, 90)), "cells_within_1e-4": int((errs <= 1e-4).sum()),
-                  # per-cell floor = the reference against its own twin with n_gas moved by ONE ulp, same cells, same settings
+                  # per-cell floor = the largest move of the reference's own end state under three one-ulp changes of its inputs (n_gas up,
+                  # n_gas down, Tgas up), same cells, same settings
                   "floor": {"median": float(np.median(floors)), "p90": float(np.percentile(floors, 90)), "max": float(floors.max()),
                             "cells_reference_moves_more_than_1e-4": int((floors > 1e-4).sum())},
                   "cells_within_max(1e-4,3*floor)": int((errs <= bound).sum()),
@@ -212,7 +240,7 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                   "nerr_by_code": {"gpu": dict(zip(names, map(int, codes_gpu))), "reference": dict(zip(names, map(int, codes_ref))),
                                    "reference_twin": dict(zip(names, map(int, codes_twin)))},
                   "nerr_total_reference": int(codes_ref.sum()), "nerr_total_reference_twin": int(codes_twin.sum()), "nerr_total_gpu": int(codes_gpu.sum())}
-        if tight is not None:  # the same comparison where trajectory noise does not limit it: RTOL 1e-8 on both sides
+        if tight is not None and hcs is None:  # the same comparison where trajectory noise does not limit it: RTOL 1e-8 on both sides
             tidx, gy = tight
             tref, tdt, _ = run_reference(cells[tidx], network, initial, params, rtol=1e-8)
             tref10, _, _ = run_reference(cells[tidx], network, initial, params, rtol=1e-10)  # how converged is the reference's own 1e-8 answer
@@ -264,6 +292,8 @@ def main():
     ap.add_argument("--cells", type=int, default=0, help="synth10k: cells per GPU (default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hints", action="store_true", help="take cells in queue order in every pass (no cost feedback)")
+    ap.add_argument("--evolT", action="store_true", help="gas temperature co-evolving with the chemistry (chemsol_params%evolT, the reference's "
+                    "production default): every cell gets a heating/cooling record (cells.andrews_grid_hc); one wave per cell (k_solve_T)")
     ap.add_argument("--nlocal-iter", type=int, default=1, help="> 1: the caller's local-iteration loop (racgpu_calc_cells) instead of one chem_evol_solve pass")
     args = ap.parse_args()
 
@@ -309,6 +339,13 @@ def main():
             cells_h = np.ascontiguousarray(full[order[lo:hi]])
         else:
             cells_h = R.cells.andrews_grid(Md=2e-2 * (1.0 + rank / 16.0))
+        hc_h = None
+        if args.evolT:
+            if args.scaling == "strong" and world > 1:
+                raise SystemExit("--evolT: weak scaling only")
+            cells_h, r_au, z_au = R.cells.andrews_grid(Md=2e-2 * (1.0 + rank / 16.0), return_geometry=True)
+            hc_h = R.cells.andrews_grid_hc(cells_h, r_au, z_au)
+            net.load_heating_cooling(DATA)
         wl = ("configs[2]: full synthetic Andrews-2009 grid, 200 columns x 100 cells = 20000 cell records (n_H 1e3..6e12 cm^-3, "
               "T 8..5000 K, per-cell t_max by the orbit rule), %s network (%s: %d species, %d reactions), %s, t_max0=%g yr, RTOL=%g, "
               "steps_reset_solver=50; every cell with the shielding factors of its record as given, i.e. frozen shielding (Jacobi relaxation "
@@ -318,6 +355,11 @@ def main():
         cells_h = R.cells.synth_batch(ncell0, seed=20240601 + rank)
         wl = ("configs[1]: %d synthetic cells per GPU (log-uniform T in [10,3000] K, n_H in [1e3,1e12] cm^-3), %s network (%s: %d species, "
               "%d reactions), %s, t_max=%g yr, RTOL=%g, steps_reset_solver=50" % (ncell0, netkey, network, nS, net.nReactions, initial, params.t_max, params.RTOL))
+    if args.evolT and args.workload != "grid":
+        raise SystemExit("--evolT goes with the grid workload")
+    if args.evolT:
+        wl += ("; GAS TEMPERATURE CO-EVOLVING (evolT) in every cell: heating/cooling records by rac-2d_amd/cells.py::andrews_grid_hc, switches of the "
+               "reference's template (README.md:135-156)")
     ncell = len(cells_h)
     yinit_h = net.init_abundances(y0, cells_h)
 
@@ -330,6 +372,8 @@ def main():
     tfin_d = torch.zeros(ncell, dtype=torch.float64, device=dev)
     qual_d = torch.zeros(ncell, dtype=torch.int32, device=dev)
     stats_d = torch.zeros((ncell, R.NSTAT), dtype=torch.int64, device=dev)
+    hc_d = torch.from_numpy(hc_h).to(dev) if args.evolT else None
+    cout_d = torch.zeros((ncell, R.NOUT), dtype=torch.float64, device=dev)
     maxn = ncell
     if world > 1:
         t = torch.tensor([ncell], dtype=torch.int64, device="cpu" if rehearsal else dev)
@@ -345,7 +389,10 @@ def main():
 
     def one_pass():
         y_d.copy_(yinit_d)
-        if args.nlocal_iter > 1:
+        if args.evolT:
+            net.evolT_solve_batch_device(params, ncell, cells_d.data_ptr(), hc_d.data_ptr(), y_d.data_ptr(), tfin_d.data_ptr(), qual_d.data_ptr(),
+                                         stats_d.data_ptr(), cout_d.data_ptr())
+        elif args.nlocal_iter > 1:
             net.calc_cells_device(params, args.nlocal_iter, ncell, cells_d.data_ptr(), y_d.data_ptr(), tfin_d.data_ptr(), qual_d.data_ptr(), stats_d.data_ptr())
         else:
             net.evol_solve_batch_device(params, ncell, cells_d.data_ptr(), y_d.data_ptr(), tfin_d.data_ptr(), qual_d.data_ptr(), stats_d.data_ptr())
@@ -400,7 +447,7 @@ def main():
 
     if rank == 0:
         nst, nfe, nje, nlu, qsum = [float(stats[:, k].sum()) for k in (0, 1, 2, 3, 6)]
-        abytes = algorithmic_bytes(nS, net.nReactions, net.nnzJ, net.nzl, net.nzu, nst, nfe, nje, nlu, qsum)
+        abytes = (algorithmic_bytes_evolT if args.evolT else algorithmic_bytes)(nS, net.nReactions, net.nnzJ, net.nzl, net.nzu, nst, nfe, nje, nlu, qsum)
         kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = abytes / (kms * 1e-3) / 1e9
         # HBM bytes per launch.  PMC counters cannot be read from inside this process; the figure is the per-cell-step traffic
@@ -411,7 +458,7 @@ def main():
         for calname in ("r3_pmc_calibration.json", "r2_pmc_calibration.json"):
             try:
                 cal = json.load(open(os.path.join(ROOT, "profiles", calname)))
-                if cal["workload"]["name"] == args.workload and cal["workload"]["network"] == network:
+                if cal["workload"]["name"] == args.workload and cal["workload"]["network"] == network and not args.evolT:
                     traffic = cal["bytes_per_cell_step_corrected"] * nst
                     traffic_src = ("calibrated, not measured in this run: profiles/%s, %.0f B per cell-step x %d cell-steps; TCC FETCH/WRITE "
                                    "counters see what crosses L2, i.e. Infinity-Cache (MALL) hits as well as HBM" % (calname, cal["bytes_per_cell_step_corrected"], int(nst)))
@@ -443,7 +490,7 @@ def main():
                          "traffic_frac_of_peak": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          # one pass = k_solve (one wave per cell) followed by k_solve_team_resume (the cells handed over at its end),
                          # with k_solve_team (cells in teams from the start) alongside: timed as a whole between two HIP events
-                         "kernel": "k_solve (+ k_solve_team, k_solve_team_resume)", "kernel_ms": kms,
+                         "kernel": "k_solve_T" if args.evolT else "k_solve (+ k_solve_team, k_solve_team_resume)", "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_cell_step": abytes / max(nst, 1.0)},
             "cell_steps_per_pass_rank0": nst, "mean_steps_per_cell": nst / ncell,
@@ -461,15 +508,21 @@ def main():
             nsample = min(ncell, 16 * cores)
             sample_idx = np.arange(nsample) * (ncell // nsample) + (ncell // nsample) // 2  # spread over the whole batch
             gpu = {"y": y_d.cpu().numpy(), "t_final": tfin_d.cpu().numpy(), "quality": qual, "nst": stats[:, 0], "nerr": stats[:, R.S_NERR],
-                   "errcodes": stats[:, R.S_ERRCODES]}
+                   "errcodes": stats[:, R.S_ERRCODES], "tgas": cout_d[:, R.O_TGAS].cpu().numpy()}
             tidx = sample_idx[::max(1, nsample // 32)][:32]
             p8 = R.default_params()
             for f in ("ATOL", "t_max", "dt_first_step", "ratio_tstep", "mxstep_per_interval", "steps_reset_solver"):
                 setattr(p8, f, getattr(params, f))
             p8.RTOL = 1e-8
             net.set_cost_hints(None)
-            gy = net.evol_solve_batch(p8, cells_h[tidx], yinit_h[tidx])["y"]
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cells_h, sample_idx, network, initial, params, gpu, nS, tight=(tidx, gy))
+            gy = None if args.evolT else net.evol_solve_batch(p8, cells_h[tidx], yinit_h[tidx])["y"]
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cells_h, sample_idx, network, initial, params, gpu, nS,
+                                                                         tight=None if args.evolT else (tidx, gy), hc=hc_h)
+            if args.evolT:
+                T0, T1 = cells_h[:, R.cells.P_TGAS], gpu["tgas"]
+                out["evolT"] = {"cells_T_still_evolving_at_end": int(cout_d[:, R.O_EVOLT_END].sum().item()),
+                                "median_abs_change_of_T_K": float(np.median(np.abs(T1 - T0))), "max_T_ratio": float(np.max(T1 / T0)),
+                                "min_T_ratio": float(np.min(T1 / T0))}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -146,8 +146,10 @@ int racgpu_reaction_rows(const racgpu_network *, double *ABC, double *T_range, c
 int racgpu_jac_pattern(const racgpu_network *, int32_t *colptr, int32_t *rowidx);
 
 /* elimination order of the species-block LU: perm[new] = old species index (1-based); *first_dense = first position (1-based) of
- * the trailing block that is factored as a dense matrix.  The reference recomputes its own (YSMP ODRV) inside DLSODES. */
-int racgpu_lu_ordering(const racgpu_network *, int32_t *perm, int32_t *first_dense);
+ * the trailing block that is factored as a dense matrix; p_storage[q] = the entry of racgpu_jac_pattern (1-based) held at position q
+ * of the engine's storage of the Newton matrix (columns in elimination order).  Any pointer may be NULL.  The reference recomputes
+ * its own ordering (YSMP ODRV) inside DLSODES. */
+int racgpu_lu_ordering(const racgpu_network *, int32_t *perm, int32_t *first_dense, int32_t *p_storage);
 /* chem_load_initial_abundances (src/chemistry.f90:1978-2024): y0[nS], neutralised and renormalised to sum(H)=1 */
 int racgpu_load_initial_abundances(const racgpu_network *, const char *path, double *y0);
 void racgpu_params_default(racgpu_params *);          /* type defaults + inp/template_configure.dat values */

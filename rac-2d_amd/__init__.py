@@ -111,7 +111,7 @@ def lib():
     L.racgpu_species_index.argtypes = [vp, C.c_char_p]
     L.racgpu_reactions.argtypes = [vp, ip, ip, ip, ip, ip, ip]
     L.racgpu_species_attrs.argtypes = [vp, dp, dp, dp, ip, ip]
-    L.racgpu_lu_ordering.argtypes = [vp, ip, ip]
+    L.racgpu_lu_ordering.argtypes = [vp, ip, ip, ip]
     L.racgpu_jac_pattern.argtypes = [vp, ip, ip]
     L.racgpu_species_elements.argtypes = [vp, ip]
     L.racgpu_reaction_rows.argtypes = [vp, dp, dp, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -321,8 +321,14 @@ class Network:
     def lu_ordering(self):
         """(perm [nS] 1-based: perm[new] = old, first position (1-based) of the dense trailing block)"""
         perm = np.zeros(self.nSpecies, np.int32); fd = C.c_int32()
-        _check(lib().racgpu_lu_ordering(self._h, _ip(perm), C.byref(fd)))
+        _check(lib().racgpu_lu_ordering(self._h, _ip(perm), C.byref(fd), None))
         return perm, fd.value
+
+    def p_storage(self):
+        """entry of jac_pattern() (1-based) held at each position of the engine's storage of the Newton matrix"""
+        ps = np.zeros(self.nnzJ, np.int32)
+        _check(lib().racgpu_lu_ordering(self._h, None, None, _ip(ps)))
+        return ps
 
     def load_initial_abundances(self, path):
         y0 = np.zeros(self.nSpecies)

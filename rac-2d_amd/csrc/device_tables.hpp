@@ -99,6 +99,7 @@ struct DevParams {
   double rt_cost_f, rt_cost_jac, rt_cost_lu; // modelled seconds per f evaluation / Jacobian / factorisation (racgpu_params)
   int n_record; // for params.t_max (record layout)
   int debug_max_calls; // developer aid (env RACGPU_DEBUG_TRACE): stop a cell after this many step calls; 0 = off
+  int debug_dump_call; // developer builds (RG_DEBUG_NEWTON, env RACGPU_DEBUG_DUMP_CALL): the step call whose first corrector pass is dumped; -1 = none
   double elco[6][7];  // BDF coefficients el(i), i = 1..nq+1, per order nq = 1..5 (DCFODE, reference src/opkda1.f:146-171)
   double tesco[6][4]; // error-test constants tesco(1..3, nq)
 };

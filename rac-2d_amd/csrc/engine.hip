@@ -914,6 +914,8 @@ static DevParams to_dev(const racgpu_params *p) {
   P.rt_cost_f = p->rt_cost_f; P.rt_cost_jac = p->rt_cost_jac; P.rt_cost_lu = p->rt_cost_lu;
   P.n_record = racgpu_n_record(p, 0.0, p->t_max);
   if (const char *e = std::getenv("RACGPU_DEBUG_TRACE")) P.debug_max_calls = std::atoi(e);
+  P.debug_dump_call = -1;
+  if (const char *e = std::getenv("RACGPU_DEBUG_DUMP_CALL")) P.debug_dump_call = std::atoi(e);
   cfode_bdf(P);
   return P;
 }
@@ -1044,10 +1046,11 @@ int racgpu_jac_pattern(const racgpu_network *h, int32_t *colptr, int32_t *rowidx
   return 0;
 }
 
-int racgpu_lu_ordering(const racgpu_network *h, int32_t *perm, int32_t *first_dense) {
+int racgpu_lu_ordering(const racgpu_network *h, int32_t *perm, int32_t *first_dense, int32_t *p_storage) {
   if (!h) return fail("null network");
   if (perm) for (int i = 0; i < h->net.nS; ++i) perm[i] = h->net.sym.perm[i] + 1;
   if (first_dense) *first_dense = h->net.sym.ns + 1;
+  if (p_storage) for (size_t q = 0; q < h->net.sym.Psrc.size(); ++q) p_storage[q] = h->net.sym.Psrc[q] + 1;
   return 0;
 }
 
@@ -1394,7 +1397,7 @@ static int evol_solve_batch_impl(racgpu_network *h, const racgpu_params *p, int6
     std::unique_ptr<DevBuf> dtrace;
     h->ws.trace = nullptr;
     if (P.debug_max_calls > 0) {
-      trace_host.assign((size_t)P.debug_max_calls * 8, 0.0);
+      trace_host.assign((size_t)P.debug_max_calls * 16 + 64 + 8 * (size_t)h->dn.npad + (size_t)h->dn.nnzJ, 0.0); // (second half and the tail: RG_DEBUG_NEWTON builds)
       dtrace = std::make_unique<DevBuf>(trace_host.data(), trace_host.size() * 8, RACGPU_MEM_HOST, true);
       h->ws.trace = (double *)dtrace->d;
     }
@@ -1437,6 +1440,16 @@ static int evol_solve_batch_impl(racgpu_network *h, const racgpu_params *p, int6
       for (int i = 0; i < P.debug_max_calls; ++i) {
         const double *tr = &trace_host[(size_t)i * 8];
         std::fprintf(stderr, "[racgpu trace] call %3d tn=%.6e h=%.6e hu=%.6e nq=%g kflag=%g nst=%g nfe=%g nje/nlu=%g\n", i, tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6], tr[7]);
+#ifdef RG_DEBUG_NEWTON
+        if (i == 0) if (const char *fn = std::getenv("RACGPU_DEBUG_DUMP_FILE")) { // the dumped corrector pass: header[64], 8 vectors of npad, P[nnzJ]
+          if (FILE *f = std::fopen(fn, "wb")) {
+            const size_t off = (size_t)P.debug_max_calls * 16, cnt = 64 + 8 * (size_t)h->dn.npad + (size_t)h->dn.nnzJ;
+            std::fwrite(&trace_host[off], sizeof(double), cnt, f); std::fclose(f);
+          }
+        }
+        const double *tx = &trace_host[(size_t)P.debug_max_calls * 8 + (size_t)i * 8];
+        std::fprintf(stderr, "[racgpu newton] call %3d m=%g del=%.3e %.3e %.3e worst(idx+1e-3*w)=%.4f %.4f %.4f w0=%.3e\n", i, tx[0], tx[1], tx[2], tx[3], tx[4], tx[5], tx[6], tx[7]);
+#endif
       }
     }
   });

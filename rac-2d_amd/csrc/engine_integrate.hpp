@@ -79,6 +79,10 @@ constexpr double kUround = 2.220446049250313e-16; // DUMACH()
 constexpr double kCcmax = 0.3, kCcmxj = 0.2, kPsmall = 1000.0 * kUround, kRbig = 0.01 / kPsmall;
 constexpr int kMaxord = 5, kMaxcor = 3, kMsbp = 20, kMxncf = 10, kMsbj = 50;
 
+#ifdef RG_DEBUG_NEWTON
+struct NewtonDbg { double del[3], big[3]; int idx[3], m; };
+static __shared__ volatile NewtonDbg g_dbg;
+#endif
 struct Lsodes { // the scalars ODEPACK keeps in COMMON /DLS001/ and /DLSS01/ plus the driver's SAVEd locals
   double conit, crate, hold, rmax, el0, h, hmxi, hu, rc, tn;
   double con0, conmin, tcrit, h0;
@@ -389,7 +393,16 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
       m = 0;
       if (pass > 0) { vec_trips<RG_VEC_TRIP, double>(n, c.npad, [&](int i0) { return bload_f64(bY, l8, i0 * 8); }, [&](int i0, double v) { if (i0 + lane < n) c.y[i0 + lane] = v; }); if constexpr (ET) g_T.y = g_T.yh[0]; }
       else wave_sync();
+#ifdef RG_DEBUG_NEWTON
+      const bool dumping = s.trace && s.ncalls == P.debug_dump_call && pass == 0 && guard == 0;
+      double *dump = s.trace ? s.trace + (size_t)s.trace_cap * 16 : nullptr;
+      auto dump_vec = [&](int slot, auto get) { if (dumping) for (int i = lane; i < n; i += 64) dump[64 + (size_t)slot * c.npad + i] = get(i); };
+      dump_vec(0, [&](int i) { return c.y[i]; }); // the predicted y
+#endif
       { const long long t0 = dev_clock(); dev_f<ET>(N, c, c.savf); cyc_add(CYC_RHS, dev_clock() - t0); } s.nfe++;
+#ifdef RG_DEBUG_NEWTON
+      dump_vec(1, [&](int i) { return c.savf[i]; }); // f(y_pred)
+#endif
       dev_mark(c, 2200 + pass);
       if (s.ipup > 0) {
         dev_prjs<ET>(N, c, s);
@@ -404,10 +417,30 @@ RG_DEV int dev_stode(const DevNet &N, const DevParams &P, const CellCtx &c, Lsod
         vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, col_off(c, 1) + i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                          [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) c.y[i] = s.h * c.savf[i] - (v.a + v.b); });
         if constexpr (ET) g_T.y = s.h * g_T.savf - (g_T.yh[1] + g_T.acor);
+#ifdef RG_DEBUG_NEWTON
+        if (dumping && m == 0) {
+          wave_sync();
+          dump_vec(2, [&](int i) { return c.y[i]; }); // the residual handed to the solve
+          dump_vec(4, [&](int i) { return bload_f64(bY, (i & 63) * 8, col_off(c, 1) + (i & ~63) * 8); }); // yh(:, 2)
+          dump_vec(5, [&](int i) { return bload_f64(bE, (i & 63) * 8, (i & ~63) * 8); });                 // inverse weights
+          dump_vec(6, [&](int i) { return bload_f64(bY, (i & 63) * 8, (i & ~63) * 8); });                 // yh(:, 1)
+          for (int e = lane; e < N.nnzJ; e += 64) dump[64 + 8 * (size_t)c.npad + e] = c.Pv[e];        // P as factored (permuted-column storage)
+          if (lane == 0) { dump[0] = s.h; dump[1] = s.el0; dump[2] = s.nq; dump[3] = s.tn; dump[4] = s.con0; dump[5] = s.jcur; dump[6] = s.rc; dump[7] = s.nst; dump[8] = s.ncalls; dump[9] = 1.0; }
+        }
+#endif
         dev_mark(c, 2400 + m);
         { const long long t0 = dev_clock(); dev_solve_neq<ET>(N, c); cyc_add(CYC_SOLVE, dev_clock() - t0); }
         dev_mark(c, 2500 + m);
         del = dev_vnorm<ET>(c, [&](int i) { return c.y[i]; }, ET ? (double)g_T.y : 0.0);
+#ifdef RG_DEBUG_NEWTON
+        if (dumping && m == 0) dump_vec(3, [&](int i) { return c.y[i]; }); // the solve's answer
+        if (s.trace_cap > 0) { // developer build: the component with the largest weighted Newton correction of this iteration
+          double big = -1.0; int idx = 0;
+          for (int i0 = 0; i0 < n; i0 += 64) { const int i = i0 + lane; const double sz = i < n ? fabs(c.y[i] * bload_f64(bE, l8, i0 * 8)) : -1.0; if (sz > big) { big = sz; idx = i; } }
+          for (int mm = 32; mm >= 1; mm >>= 1) { const double ob = __shfl_xor(big, mm, 64); const int oi = __shfl_xor(idx, mm, 64); if (ob > big || (ob == big && oi < idx)) { big = ob; idx = oi; } }
+          g_dbg.del[m < 3 ? m : 2] = del; g_dbg.idx[m < 3 ? m : 2] = uniform_i(idx); g_dbg.big[m < 3 ? m : 2] = uniform_d(big); g_dbg.m = m;
+        }
+#endif
         const double el1 = P.elco[s.nq][1];
         vec_trips<RG_VEC_TRIP, D2>(n, c.npad, [&](int i0) { return D2{bload_f64(bY, l8, i0 * 8), bload_f64(bA, l8, i0 * 8)}; },
                          [&](int i0, D2 v) { const int i = i0 + lane; if (i < n) { const double a = v.b + c.y[i]; bstore_f64(bA, l8, i0 * 8, a); c.y[i] = v.a + el1 * a; } });
@@ -780,6 +813,11 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
       if (s.trace && s.ncalls < s.trace_cap && lane == 0) {
         double *tr = s.trace + (size_t)s.ncalls * 8;
         tr[0] = s.tn; tr[1] = s.h; tr[2] = s.hu; tr[3] = s.nq; tr[4] = kflag; tr[5] = s.nst; tr[6] = s.nfe; tr[7] = s.nje * 10000.0 + s.nlu;
+#ifdef RG_DEBUG_NEWTON
+        double *tx = s.trace + (size_t)s.trace_cap * 8 + (size_t)s.ncalls * 8; // second block: the last corrector pass of the call
+        tx[0] = g_dbg.m; for (int k = 0; k < 3; ++k) { tx[1 + k] = g_dbg.del[k]; tx[4 + k] = g_dbg.idx[k] + 1e-3 * fmin(g_dbg.big[k], 900.0); }
+        tx[7] = g_dbg.big[0];
+#endif
       }
       if (++s.ncalls >= s.trace_cap) { istate = -3; dev_finish<ET>(c, s, t); return; }
     }

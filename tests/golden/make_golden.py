@@ -291,6 +291,23 @@ def main_grid64():
                yend_ulp=np.array([c["yend"] for c in ulp]), scalars_ulp=np.array([c["scalars"][:3] for c in ulp]), errcodes_ulp=ec_ulp,
                yend_tight=np.array([c["yend"] for c in tight]), scalars_tight=np.array([c["scalars"][:3] for c in tight]), errcodes_tight=ec_t,
                yend_tighter=np.array([c["yend"] for c in tighter]), scalars_tighter=np.array([c["scalars"][:3] for c in tighter]))
+    # five more one-ulp twins: one sample of a chaotic quantity underestimates it
+    kinds = [("n-1", 2, -1), ("n+2", 2, 2), ("T+1", 0, 1), ("T-1", 0, -1), ("zeta+1", 9, 1)]
+    nS_ = out["yend"].shape[1] - 1
+    fl = np.zeros((len(idx), len(kinds) + 1)); ne = np.zeros((len(idx), len(kinds) + 1))
+    for i in range(len(idx)):
+        m = out["yend"][i][:nS_] >= 1e-6
+        fl[i, 0] = np.max(np.abs(out["yend_ulp"][i][:nS_][m] - out["yend"][i][:nS_][m]) / out["yend"][i][:nS_][m]); ne[i, 0] = out["scalars_ulp"][i, 2]
+    for j, (name, col, steps) in enumerate(kinds):
+        c2 = cells.copy()
+        for _ in range(abs(steps)):
+            c2[:, col] = np.nextafter(c2[:, col], np.inf if steps > 0 else 0.0)
+        c2[:, 5] = c2[:, 2] * c2[:, 6]
+        tw, _ = run_ref_parallel(network, initial, c2, 1e-4, 1e6)
+        for i, o in enumerate(tw):
+            m = out["yend"][i][:nS_] >= 1e-6
+            fl[i, j + 1] = np.max(np.abs(o["yend"][:nS_][m] - out["yend"][i][:nS_][m]) / out["yend"][i][:nS_][m]); ne[i, j + 1] = o["scalars"][2]
+    out.update(twin_kinds=np.array(["n+1"] + [k[0] for k in kinds]), floor_twins=fl, nerr_twins=ne)
     fn = os.path.join(HERE, "grid64_grain.npz")
     np.savez_compressed(fn, **out)
     nS = out["yend"].shape[1] - 1
@@ -325,6 +342,17 @@ def main_evolT():
     hc_ulp = hc.copy(); hc_ulp[:, C.H_N_DUSTS] = cells_ulp[:, 5]
     ulp, _ = run_ref(network, initial, cells_ulp, 1e-4, 1e6, 50, 0, hc=hc_ulp)
     tight, _ = run_ref(network, initial, cells, 1e-8, 1e6, 50, 0, hc=hc)
+    # more one-ulp twins (one sample underestimates a chaotic quantity): n_gas down, Tgas up / down, zeta_CR up
+    floors = []
+    for col, up in ((2, False), (0, True), (0, False), (9, True)):
+        c2 = cells.copy(); c2[:, col] = np.nextafter(c2[:, col], np.inf if up else 0.0); c2[:, 5] = c2[:, 2] * c2[:, 6]
+        h2 = hc.copy(); h2[:, C.H_N_DUSTS] = c2[:, 5]
+        tw, _ = run_ref(network, initial, c2, 1e-4, 1e6, 50, 0, hc=h2)
+        row = []
+        for i, o in enumerate(tw):
+            ye = cfg[i]["yend"]; m = np.r_[ye[:nS] >= 1e-6, True]
+            row.append(float(np.max(np.abs(o["yend"][m] - ye[m]) / ye[m])))
+        floors.append(row)
     IA, JA = meta["pattern"][:NEQ + 1], meta["pattern"][NEQ + 1:]
     # the T row (entries of row NEQ in the columns of the ten special species) and the T column of jac0
     ten = ["H2", "H", "E-", "C", "C+", "O", "O2", "CO", "H2O", "OH"]
@@ -353,7 +381,7 @@ def main_evolT():
                yend_ulp=np.array([c["yend"] for c in ulp]), scalars_ulp=np.array([c["scalars"][:3] for c in ulp]), evolTend_ulp=np.array([c["evolTend"][0] for c in ulp]),
                yend_tight=np.array([c["yend"] for c in tight]), scalars_tight=np.array([c["scalars"][:3] for c in tight]),
                Trecord_tight=pad([c["Trecord"] for c in tight]), evolTend_tight=np.array([c["evolTend"][0] for c in tight]),
-               heat_rxn=meta["heat_rxn"], heat_val=meta["heat_val"])
+               heat_rxn=meta["heat_rxn"], heat_val=meta["heat_val"], floor_twins=np.array(floors).T)
     fn = os.path.join(HERE, "evolT_grain.npz")
     np.savez_compressed(fn, **out)
     for i in range(len(idx)):

@@ -7,5 +7,5 @@ mkdir -p build/var_$name
 cd rac-2d_amd/csrc
 F="--offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -mllvm -disable-machine-licm"
 hipcc -O3 -fPIC -std=c++17 -I../../include $F "$@" -c engine.hip -o ../../build/var_$name/engine.o
-hipcc -shared -fPIC -o ../../build/libvar_$name.so ../../build/var_$name/engine.o network.o
+hipcc -shared -fPIC -o ../../build/libvar_$name.so ../../build/var_$name/engine.o network.o hc_host.o multi.o -ldl -lpthread
 echo built build/libvar_$name.so
