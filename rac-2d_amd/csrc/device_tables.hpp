@@ -86,6 +86,7 @@ struct DevNet {
   // type-11 special indices (0-based, -1 none)
   int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;
   int i_H2;                  // hand-off test (reference src/disk.f90:1716-1721)
+  int grain_conserved;       // 1: every reaction has as many Grain0/Grain-/Grain+ among its reactants as among its products (dev_rhs)
   int r_h2form;              // last reaction whose coefficient the reference copies into R_H2_form_rate_coeff (-1 none)
   const uint8_t *s_tolclass; // 0 generic, 1 one of the ten special species, 2 Grain0/+/-, 3 surface species (applied in that order)
   const int8_t *s_charge;    // elements(1, :) of every species (rectify_abundances, reference src/chemistry.f90:2170-2201)

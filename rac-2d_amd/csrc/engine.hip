@@ -815,6 +815,18 @@ void racgpu_network::upload() {
   }
   set_ref_layout();
   dn.i_H2 = h.idx10[0] - 1;
+  {
+    // The number of grains is conserved by every reaction of the reference's networks (charging and recombination move a grain between
+    // Grain0 / Grain- / Grain+).  dev_rhs then makes d/dt of their sum exactly zero (see there); a network that breaks the rule is left alone.
+    dn.grain_conserved = h.i_Grain0 > 0 ? 1 : 0;
+    auto is_grain = [&](int sp) { return sp > 0 && (sp == h.i_Grain0 || sp == h.i_GrainM || sp == h.i_GrainP); };
+    for (const Reaction &x : h.R) {
+      int a = 0, b = 0;
+      for (int k = 0; k < x.n_reac; ++k) a += is_grain(x.reac[k]);
+      for (int k = 0; k < x.n_prod; ++k) b += is_grain(x.prod[k]);
+      if (a != b && h.kind((int)(&x - &h.R[0])) != K_NONE) dn.grain_conserved = 0;
+    }
+  }
   dn.r_h2form = -1; // chem_cal_rates stores the coefficient of every itype-0 and every gH-first itype-63 reaction in turn: the last one stays
   for (int r = 0; r < nR; ++r)
     if (h.R[r].itype == 0 || (h.R[r].itype == 63 && h.R[r].rname[0] == "gH")) dn.r_h2form = r;
