@@ -10,7 +10,7 @@ grid64 from the unmodified reference):
 Bounds (species with X >= 1e-6):
   * RTOL 1e-4: BASELINE.json's bar 1e-4, or 3x the cell's own floor where the reference itself moves by more than that;
   * RTOL 1e-8: 5e-6 + 3x the reference's own 1e-8 <-> 1e-10 distance on that cell (both runs sit within their truncation error of
-    the exact solution; the reference's is up to 2.5e-6 here) in cells cooler than 250 K, 1e-4 in the hot ones (see the test);
+    the exact solution; the reference's is up to 2.5e-6 here);
   * t_final and quality equal; NERR within what the reference's 1-ulp twin shows against the reference itself (up to 2 per
     cell, all of them ISTATE -4 / -5: which step fails its error test is decided at rounding level).
 """
@@ -77,11 +77,9 @@ def test_grid_cells_error_returns_are_the_references_kind(racgpu, grid64):
 
 
 def test_grid_cells_tight_tolerance_pair(racgpu, grid64):
-    """RTOL 1e-8 on both sides, the reference's wall-clock guards and the engine's modelled ones off.  Measured:
-    in cells cooler than ~250 K the two agree to a few 1e-7 (the reference's own RTOL 1e-8 <-> 1e-10 distance); in hot cells, where
-    H+ sits in a fast charge-exchange equilibrium, the Newton iteration of BOTH codes becomes rounding-limited below RTOL ~1e-7 (the
-    reference's cell 9711: 2524 Jacobians instead of ~100) and the engine reaches that regime a decade earlier in RTOL (cell 39:
-    219 Jacobians at RTOL 1e-6 against 79), ending up to 6e-5 off in H+.  The bound there is BASELINE.json's 1e-4."""
+    """RTOL 1e-8 on both sides, the reference's wall-clock guards and the engine's modelled ones off: the pin that trajectory noise does
+    not limit.  Measured: max 1.5e-6 (H+ at 2900 K), median 9e-9 over the 64 cells; the reference's own RTOL 1e-8 <-> 1e-10 distance is up
+    to 2.5e-6.  (Before dev_rhs balanced the grain number exactly the hot cells were up to 6e-5 off in H+: DESIGN.md section 2.)"""
     g, net, y0 = grid64
     nS = net.nSpecies
     p = racgpu.default_params()
@@ -92,14 +90,17 @@ def test_grid_cells_tight_tolerance_pair(racgpu, grid64):
         ref, truth = g["yend_tight"][c][:nS], g["yend_tighter"][c][:nS]
         own = major_relerr(ref, truth)  # the reference's RTOL 1e-8 run against its RTOL 1e-10 run
         err = major_relerr(out["y"][c], ref)
-        hot = g["cells"][c, 0] >= 250.0
-        if err > (1e-4 if hot else 5e-6 + 3.0 * own):
+        if err > 5e-6 + 3.0 * own:
             bad.append((int(g["grid_idx"][c]), float(g["cells"][c, 0]), err, own))
+        # and against the better truth the engine's RTOL 1e-8 run is as good as the reference's own
+        assert major_relerr(out["y"][c], truth) <= 5e-6 + 3.0 * own, (int(g["grid_idx"][c]), major_relerr(out["y"][c], truth), own)
     assert not bad, bad
     same_nerr = out["stats"][:, racgpu.S_NERR] == g["scalars_tight"][:, 2]
     assert (out["t_final"][same_nerr] == g["scalars_tight"][same_nerr, 0]).all()
-    assert (out["quality"][same_nerr] == g["scalars_tight"][same_nerr, 1].astype(int)).all()
-    assert np.max(np.abs(out["stats"][:, racgpu.S_NERR] - g["scalars_tight"][:, 2])) <= 1  # (4 of 64 cells differ by one on either side)
+    assert (out["quality"] == g["scalars_tight"][:, 1].astype(int)).all()
+    assert np.max(np.abs(out["stats"][:, racgpu.S_NERR] - g["scalars_tight"][:, 2])) <= 1  # (a handful of the 64 cells differ by one on either side)
+    # the engine needs no more steps than the reference's restatement does on these cells (oracle: 3545 ... 9435 on the ten hardest)
+    assert out["stats"][:, racgpu.S_NST].max() < 9000
 
 
 def test_grid_cells_rate_coefficients(racgpu, grid64):
