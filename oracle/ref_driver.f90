@@ -13,7 +13,8 @@
 program ref_driver
   use chemistry
   use heating_cooling
-  use disk, only: a_disk
+  use disk, only: a_disk, write_header, disk_save_results_write
+  use data_struct, only: type_cell
   use trivials, only: double2str
   implicit none
   external chem_ode_f, chem_ode_jac
@@ -33,7 +34,9 @@ program ref_driver
   ! cell = the fields of the cell record that only the heating/cooling terms read (layout: include/racgpu.h, RACGPU_H_*);
   ! enthalpy: the species-enthalpy file (chemical heating); transitions_dir: where the ion-cooling tables N+/Si+/Fe+_LUT.bin lie.
   ! The heating/cooling switches are the README template's (README.md:135-156).
-  integer :: evolT, may_switch_T
+  integer :: evolT, may_switch_T, dump_iter_file
+  type(type_cell), pointer :: cc
+  integer :: fI
   character(len=256) :: hc_file, enthalpy, transitions_dir
   integer, parameter :: NHC = 28
   double precision :: hpar(NHC), Tdot
@@ -41,7 +44,7 @@ program ref_driver
   namelist /ref_run/ chem_dir, network, initial, out_dir, cell_file, ncell, &
     rtol, atol, dt_first_step, ratio_tstep, t_max, mxstep, steps_reset, h2_moeq, &
     dump_jac, dump_record_every, solve, nlocal_iter, tol_j, y_override, special_gH_mobi, dump_analysis, &
-    evolT, may_switch_T, hc_file, enthalpy, transitions_dir
+    evolT, may_switch_T, hc_file, enthalpy, transitions_dir, dump_iter_file
   double precision, allocatable :: abund(:)
   double precision :: t_final, t_end, dt0, tmp, ov_val
   integer :: jj, isav, qual_cell, ov_cell, ov_spe, fO, ios
@@ -58,7 +61,7 @@ program ref_driver
   t_max = 1D6; mxstep = 6000; steps_reset = 50; h2_moeq = .false.
   dump_jac = 1; dump_record_every = 0; solve = 1
   nlocal_iter = 1; tol_j = 1; y_override = ''; special_gH_mobi = .false.; dump_analysis = 0
-  evolT = 0; may_switch_T = 1; hc_file = ''; enthalpy = ''; transitions_dir = './transitions/'
+  evolT = 0; may_switch_T = 1; hc_file = ''; enthalpy = ''; transitions_dir = './transitions/'; dump_iter_file = 0
   open(newunit=fU, file=trim(nml_file), status='old', action='read')
   read(fU, nml=ref_run)
   close(fU)
@@ -164,6 +167,18 @@ program ref_driver
     write(fC, '(ES25.17E3)') chemsol_stor%y0(i)
   end do
   close(fC)
+
+  if (dump_iter_file .ne. 0) then
+    ! the reference's own iter_NNNN.dat writer (write_header, disk_save_results_write: src/disk.f90:2745-3073) on ONE cell whose every
+    ! printed field holds a number that says which field it is: field k of the row prints k + k/1000 (integers: k), abundance i: i * 1e-3
+    allocate(cc); allocate(cc%par); allocate(cc%h_c_rates)
+    allocate(cc%abundances(nS_probe()), cc%col_den_toISM(chem_idx_some_spe%nItem), cc%col_den_toStar(chem_idx_some_spe%nItem))
+    call fill_probe_cell(cc)
+    open(newunit=fI, file=trim(out_dir)//'/iter_probe.dat', status='replace')
+    call write_header(fI)
+    call disk_save_results_write(fI, cc)
+    close(fI)
+  end if
 
   open(newunit=fU, file=trim(cell_file), status='old', action='read')
   do ic = 1, ncell
@@ -460,6 +475,62 @@ program ref_driver
   end do
   close(fU)
 contains
+  integer function nS_probe()
+    nS_probe = chem_species%nSpecies
+  end function nS_probe
+
+  subroutine fill_probe_cell(c)
+    ! field k of disk_save_results_write's list gets the value k + k/1000 (the four integer counters: k)
+    type(type_cell), pointer, intent(inout) :: c
+    integer :: i
+    double precision :: v(148)
+    do i = 1, 148
+      v(i) = dble(i) + dble(i) * 1D-3
+    end do
+    c%converged = .true.; c%quality = 2
+    c%par%ab_count_dust = 4; c%par%sc_count_HI = 5; c%par%ab_count_water = 6
+    c%par%t_final = v(7); c%xmin = v(8); c%xmax = v(9); c%ymin = v(10); c%ymax = v(11)
+    c%par%n_gas = v(12); c%par%Tgas = v(13); c%par%Tdust = v(14); c%par%Tdusts = v(15:18); c%par%n_dusts = v(19:22); c%par%ndust_tot = v(23)
+    c%par%rho_dusts = v(24:27); c%par%sig_dusts = v(28:31); c%par%sigdust_ave = v(32); c%par%ratioDust2GasMass = v(33)
+    c%par%ratioDust2HnucNum = v(34); c%par%dust_depletion = v(35); c%par%mgas_cell = v(36); c%par%mdust_tot = v(37)
+    c%par%pressure_thermal = v(38); c%par%area_T = 1D0; c%par%gravity_acc_z = v(39)
+    c%par%en_gain_tot = v(40); c%par%en_gain_abso_tot = v(41); c%par%en_exchange_tot = v(42)
+    c%par%en_gains = (/v(43), v(45), v(47), v(49)/); c%par%en_exchange = (/v(44), v(46), v(48), v(50)/)
+    c%par%flux_tot = v(51); c%par%flux_Xray = v(52); c%par%flux_UV = v(53) * phy_Habing_energy_flux_CGS; c%par%flux_Lya = v(54)
+    c%par%flux_Vis = v(55); c%par%flux_NIR = v(56); c%par%flux_MIR = v(57); c%par%flux_FIR = v(58)
+    c%par%dir_tot_r = v(59); c%par%dir_tot_z = v(60); c%par%aniso_tot = v(61); c%par%dir_Xray_r = v(62); c%par%dir_Xray_z = v(63); c%par%aniso_Xray = v(64)
+    c%par%dir_UV_r = v(65); c%par%dir_UV_z = v(66); c%par%aniso_UV = v(67); c%par%dir_Lya_r = v(68); c%par%dir_Lya_z = v(69); c%par%aniso_Lya = v(70)
+    c%par%dir_Vis_r = v(71); c%par%dir_Vis_z = v(72); c%par%aniso_Vis = v(73); c%par%dir_NIR_r = v(74); c%par%dir_NIR_z = v(75); c%par%aniso_NIR = v(76)
+    c%par%dir_MIR_r = v(77); c%par%dir_MIR_z = v(78); c%par%aniso_MIR = v(79); c%par%dir_FIR_r = v(80); c%par%dir_FIR_z = v(81); c%par%aniso_FIR = v(82)
+    c%par%Av_toISM = v(83); c%par%Av_toStar = v(84); c%par%G0_UV_toISM = v(85); c%par%G0_UV_toStar = v(86); c%par%G0_Lya_atten = v(87)
+    c%par%phflux_Lya = v(88); c%par%zeta_Xray_H2 = v(89); c%par%Ncol_toISM = v(90); c%par%Ncol_toStar = v(91)
+    c%col_den_toISM = 0D0; c%col_den_toStar = 0D0
+    c%col_den_toISM(chem_idx_some_spe%iiH2) = v(92); c%col_den_toISM(chem_idx_some_spe%iiH2O) = v(93)
+    c%col_den_toISM(chem_idx_some_spe%iiOH) = v(94); c%col_den_toISM(chem_idx_some_spe%iiCO) = v(95)
+    c%col_den_toStar(chem_idx_some_spe%iiH2) = v(96); c%col_den_toStar(chem_idx_some_spe%iiH2O) = v(97)
+    c%col_den_toStar(chem_idx_some_spe%iiOH) = v(98); c%col_den_toStar(chem_idx_some_spe%iiCO) = v(99)
+    c%par%f_selfshielding_toISM_H2 = v(100); c%par%f_selfshielding_toISM_H2O = v(101); c%par%f_selfshielding_toISM_OH = v(102)
+    c%par%f_selfshielding_toISM_CO = v(103); c%par%f_selfshielding_toStar_H2 = v(104); c%par%f_selfshielding_toStar_H2O = v(105)
+    c%par%f_selfshielding_toStar_OH = v(106); c%par%f_selfshielding_toStar_CO = v(107); c%par%R_H2_form_rate = v(108)
+    associate(r => c%h_c_rates)
+      r%hc_net_rate = v(109); r%heating_photoelectric_small_grain_rate = v(110); r%heating_formation_H2_rate = v(111)
+      r%heating_cosmic_ray_rate = v(112); r%heating_vibrational_H2_rate = v(113); r%heating_ionization_CI_rate = v(114)
+      r%heating_photodissociation_H2_rate = v(115); r%heating_photodissociation_H2O_rate = v(116); r%heating_photodissociation_OH_rate = v(117)
+      r%heating_Xray_Bethell_rate = v(118); r%heating_viscosity_rate = v(119); r%heating_chem = v(120)
+      r%cooling_photoelectric_small_grain_rate = v(121); r%cooling_vibrational_H2_rate = v(122); r%cooling_gas_grain_collision_rate = v(123)
+      r%cooling_OI_rate = v(124); r%cooling_CII_rate = v(125); r%cooling_NII_rate = v(126); r%cooling_SiII_rate = v(127); r%cooling_FeII_rate = v(128)
+      r%cooling_OH_rot_rate = v(129); r%cooling_Neufeld_H2O_rate_rot = v(130); r%cooling_Neufeld_H2O_rate_vib = v(131)
+      r%cooling_Neufeld_CO_rate_rot = v(132); r%cooling_Neufeld_CO_rate_vib = v(133); r%cooling_Neufeld_H2_rot_rate = v(134)
+      r%cooling_LymanAlpha_rate = v(135); r%cooling_free_bound_rate = v(136); r%cooling_free_free_rate = v(137)
+    end associate
+    c%par%alpha_viscosity = v(138); c%par%ambipolar_f = v(139); c%par%ion_charge = v(140); c%par%velo_Kepler = v(141); c%par%omega_Kepler = v(142)
+    c%par%velo_gradient = v(143); c%par%sound_speed = v(144); c%par%velo_width_turb = v(145); c%par%coherent_length = v(146)
+    c%par%SitesPerGrain = v(147); c%par%n_mol_on_grain = v(148)
+    do i = 1, chem_species%nSpecies
+      c%abundances(i) = dble(i) * 1D-3
+    end do
+  end subroutine fill_probe_cell
+
   subroutine dump_hc(fC, tag)
     ! the 28 heating/cooling terms of the last chem_ode_f call (heating_minus_cooling, src/heating_cooling.f90:1204-1269), erg s-1 cm-3,
     ! in the order of type_heating_cooling_rates_list (src/data_struct.f90:489-520): net first

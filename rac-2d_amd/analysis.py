@@ -150,3 +150,107 @@ def write_contributions(f, net, t, y, rates, cell, species, tables=None):
                     _es(rr["ABC"][k, 0], 12, 2), rr["ABC"][k, 1], rr["ABC"][k, 2], rr["T_range"][k, 0], rr["T_range"][k, 1]))
                 if c <= lst[0][1] * 1e-6:
                     break
+
+
+# ---------------------------------------------------------------------------------------------------------
+# iter_NNNN.dat: the per-cell ASCII table of a global iteration (reference write_header / disk_save_results_write,
+# src/disk.f90:2745-2902, 2905-3073).  Row = 2I5, 4I14, 142 ES14.5E3, nSpecies ES14.5E3; header = '!' + the column names right-aligned
+# in the same widths (cvg 4, qual 5, everything else 14).  The reference's readers (utils_python/draw/misc.py::load_data_as_dic) take
+# the header's whitespace-separated words as keys and numpy.loadtxt(comments='!') columns as values.
+# ---------------------------------------------------------------------------------------------------------
+ITER_INT_COLUMNS = ("cvg", "qual", "cr_count", "abc_dus", "scc_HI", "abc_wat")
+ITER_REAL_COLUMNS = (
+    "t_final", "rmin", "rmax", "zmin", "zmax", "n_gas", "Tgas", "Tdust", "Tdust1", "Tdust2", "Tdust3", "Tdust4", "ndust_1", "ndust_2", "ndust_3",
+    "ndust_4", "ndust_t", "rhodus_1", "rhodus_2", "rhodus_3", "rhodus_4", "sigdus_1", "sigdus_2", "sigdus_3", "sigdus_4", "sigd_av", "d2gmas",
+    "d2gnum", "deplet", "mg_cell", "md_cell", "presr_t", "presr_g", "egain_d", "egain_ab", "egain_e", "egain_d1", "egain_e1", "egain_d2",
+    "egain_e2", "egain_d3", "egain_e3", "egain_d4", "egain_e4", "flx_tot", "flx_Xray", "G0_UV", "flx_Lya", "flx_Vis", "flx_NIR", "flx_MIR",
+    "flx_FIR", "vr_tot", "vz_tot", "ani_tot", "vr_Xray", "vz_Xray", "ani_Xray", "vr_UV", "vz_UV", "ani_UV", "vr_Lya", "vz_Lya", "ani_Lya", "vr_Vis",
+    "vz_Vis", "ani_Vis", "vr_NIR", "vz_NIR", "ani_NIR", "vr_MIR", "vz_MIR", "ani_MIR", "vr_FIR", "vz_FIR", "ani_FIR", "Av_ISM", "Av_Star", "UV_G0_I",
+    "UV_G0_S", "LyAG0_a", "LyANF0", "zeta_X", "Ncol_I", "Ncol_S", "N_H2_I", "N_H2O_I", "N_OH_I", "N_CO_I", "N_H2_S", "N_H2O_S", "N_OH_S", "N_CO_S",
+    "f_H2_I", "f_H2O_I", "f_OH_I", "f_CO_I", "f_H2_S", "f_H2O_S", "f_OH_S", "f_CO_S", "R_H2_fo", "hc_net", "h_ph_gr", "h_fo_H2", "h_cosmi", "h_vi_H2",
+    "h_io_CI", "h_ph_H2", "h_ph_wa", "h_ph_OH", "h_Xray", "h_visco", "h_chem", "c_el_gr", "c_vi_H2", "c_gg_co", "c_OI", "c_CII", "c_NII", "c_SiII",
+    "c_FeII", "c_OH_ro", "c_wa_ro", "c_wa_vi", "c_CO_ro", "c_CO_vi", "c_H2_ro", "c_LyAlp", "c_fb", "c_ff", "alpha", "am", "ion_cha", "v_Kep", "w_Kep",
+    "dv_dr", "c_sound", "dv_turb", "l_coher", "nsit_gr", "nmol_gr")
+assert len(ITER_REAL_COLUMNS) == 142
+# where the 29 values of type_heating_cooling_rates_list (HC_TERM_NAMES order) sit in the row: the writer's order differs from the type's
+_HC_ROW_ORDER = ("hc_net", "h_ph_gr", "h_fo_H2", "h_cosmi", "h_vi_H2", "h_io_CI", "h_ph_H2", "h_ph_wa", "h_ph_OH", "h_Xray", "h_visco", "h_chem",
+                 "c_el_gr", "c_vi_H2", "c_gg_co", "c_OI", "c_CII", "c_wa_ro", "c_wa_vi", "c_CO_ro", "c_CO_vi", "c_H2_ro", "c_LyAlp", "c_fb", "c_ff",
+                 "c_NII", "c_SiII", "c_FeII", "c_OH_ro")
+
+
+def iter_file_columns(cells, y, t_final, quality, cell_out, names, hc=None, hc_terms=None, geometry=None, col_den=None, converged=None):
+    """The columns of iter_NNNN.dat this path owns or is handed, as a dict name -> [ncell] array; everything that belongs to subsystems
+    out of scope here (photon counters, fluxes and their anisotropies, masses, pressures, dust energy exchange) is what the reference
+    writes for a cell those subsystems have not touched: zero.
+      cells [ncell, NPAR], y [ncell, nS] (handed-back abundances), t_final, quality, cell_out [ncell, NOUT] of a solve call;
+      hc [ncell, NHC] heating/cooling records (dust components, omega_Kepler, ...), hc_terms [ncell, 29] (Network.ode_f_evolT terms);
+      geometry = (rmin, rmax, zmin, zmax) arrays [AU]; col_den = dict with N_H2_I ... N_CO_S; converged [ncell] 0/1."""
+    from . import cells as Cc
+    cells = np.asarray(cells, dtype=np.float64); n = cells.shape[0]
+    col = {k: np.zeros(n) for k in ITER_INT_COLUMNS + ITER_REAL_COLUMNS}
+    col["cvg"] = np.zeros(n) if converged is None else np.asarray(converged, dtype=np.float64)
+    col["qual"] = np.asarray(quality, dtype=np.float64)
+    col["t_final"] = np.asarray(t_final, dtype=np.float64)
+    if geometry is not None:
+        col["rmin"], col["rmax"], col["zmin"], col["zmax"] = (np.asarray(a, dtype=np.float64) for a in geometry)
+    co = np.asarray(cell_out, dtype=np.float64)
+    col["n_gas"] = cells[:, Cc.P_NGAS]; col["Tgas"] = np.where(np.isfinite(co[:, 3]), co[:, 3], cells[:, Cc.P_TGAS]); col["Tdust"] = cells[:, Cc.P_TDUST]
+    col["ndust_t"] = cells[:, Cc.P_NDUST]; col["sigd_av"] = cells[:, Cc.P_SIGDUST]; col["d2gnum"] = cells[:, Cc.P_D2H]
+    col["Av_ISM"] = cells[:, Cc.P_AV_ISM]; col["Av_Star"] = cells[:, Cc.P_AV_STAR]; col["UV_G0_I"] = cells[:, Cc.P_G0_ISM]; col["UV_G0_S"] = cells[:, Cc.P_G0_STAR]
+    col["LyANF0"] = cells[:, Cc.P_LYA]; col["LyAG0_a"] = cells[:, Cc.P_LYA] / 6e7  # G0_Lya_atten = phflux_Lya / phy_Habing_photon_flux_CGS (src/disk.f90:1880)
+    col["zeta_X"] = cells[:, Cc.P_ZETA_X]; col["Ncol_I"] = cells[:, Cc.P_NCOL_ISM]
+    for k, slot in (("f_H2_I", Cc.P_FSS_ISM_H2), ("f_H2O_I", Cc.P_FSS_ISM_H2O), ("f_OH_I", Cc.P_FSS_ISM_OH), ("f_CO_I", Cc.P_FSS_ISM_CO),
+                    ("f_H2_S", Cc.P_FSS_STAR_H2), ("f_H2O_S", Cc.P_FSS_STAR_H2O), ("f_OH_S", Cc.P_FSS_STAR_OH), ("f_CO_S", Cc.P_FSS_STAR_CO)):
+        col[k] = cells[:, slot]
+    col["nsit_gr"] = cells[:, Cc.P_SITES]; col["nmol_gr"] = np.nan_to_num(co[:, 1])
+    # R_H2_form_rate = get_H2_form_rate(R_H2_form_rate_coeff, X(gH), X(H), n_gas) (src/disk.f90:4302-4315)
+    names = list(names); y = np.asarray(y, dtype=np.float64)
+    coeff = np.nan_to_num(co[:, 0])
+    if "gH" in names:
+        col["R_H2_fo"] = coeff * y[:, names.index("gH")] ** 2 * cells[:, Cc.P_NGAS]
+    elif "H" in names:
+        col["R_H2_fo"] = coeff * y[:, names.index("H")] * cells[:, Cc.P_NGAS]
+    if hc is not None:
+        hc = np.asarray(hc, dtype=np.float64)
+        for i in range(4):
+            col["Tdust%d" % (i + 1)] = hc[:, Cc.H_TDUSTS + i]; col["ndust_%d" % (i + 1)] = hc[:, Cc.H_N_DUSTS + i]
+            col["sigdus_%d" % (i + 1)] = hc[:, Cc.H_SIG_DUSTS + i]; col["egain_d%d" % (i + 1)] = hc[:, Cc.H_EN_GAINS + i]
+        col["egain_d"] = hc[:, Cc.H_EN_GAIN_TOT]; col["deplet"] = hc[:, Cc.H_DUST_DEPL]; col["Ncol_S"] = hc[:, Cc.H_NCOL_STAR]
+        col["w_Kep"] = hc[:, Cc.H_OMEGA_K]; col["dv_turb"] = hc[:, Cc.H_DV_TURB]; col["l_coher"] = hc[:, Cc.H_COHERENT]
+    if hc_terms is not None:
+        ht = np.asarray(hc_terms, dtype=np.float64)
+        for k, name in enumerate(_HC_ROW_ORDER):
+            col[name] = ht[:, k]
+    if col_den is not None:
+        for k, v in col_den.items():
+            col[k] = np.asarray(v, dtype=np.float64)
+    return col
+
+
+def _f_es14(v):
+    """Fortran ES14.5E3 of one value"""
+    if not np.isfinite(v):
+        return "%14s" % ("NaN" if np.isnan(v) else ("Inf" if v > 0 else "-Inf"))
+    s = "%.5E" % v
+    mant, ex = s.split("E")
+    return "%14s" % ("%sE%s%03d" % (mant, ex[0], int(ex[1:])))
+
+
+def write_iter_dat(path, names, columns, y):
+    """iter_NNNN.dat in the reference's layout (write_header + one disk_save_results_write row per cell)."""
+    names = list(names); y = np.asarray(y, dtype=np.float64)
+    with open(path, "w") as f:
+        f.write("!" + "cvg".rjust(4) + "qual".rjust(5) + "".join(k.rjust(14) for k in ITER_INT_COLUMNS[2:] + ITER_REAL_COLUMNS)
+                + "".join("  " + ("%-12s" % nm)[:12] for nm in names) + "\n")  # (A14 of a character(12) name: two blanks, then the name)
+        for c in range(y.shape[0]):
+            f.write("%5d%5d" % (int(columns["cvg"][c]), int(columns["qual"][c])) + "".join("%14d" % int(columns[k][c]) for k in ITER_INT_COLUMNS[2:])
+                    + "".join(_f_es14(float(columns[k][c])) for k in ITER_REAL_COLUMNS) + "".join(_f_es14(float(v)) for v in y[c]) + "\n")
+
+
+def load_iter_dat(path):
+    """The parsing rules of the reference's own reader (utils_python/draw/misc.py::load_data_as_dic): keys = the whitespace-separated
+    words of the first line without its first character, values = the columns of numpy.loadtxt(comments='!')."""
+    data = np.loadtxt(path, comments="!", ndmin=2)
+    with open(path) as f:
+        keys = f.readline()[1:].split()
+    return {k: data[:, i] for i, k in enumerate(keys)}

@@ -393,6 +393,21 @@ def main_evolT():
     print("wrote", fn, os.path.getsize(fn) // 1024, "KiB")
 
 
+def main_iterprobe():
+    """tests/golden/iter_probe_grain.dat: the reference's own iter_NNNN.dat writer (write_header + disk_save_results_write, src/disk.f90:2745-
+    3073) on one cell whose k-th printed field holds k + k/1000 (ref_driver, dump_iter_file = 1): pins names, order, widths and formats."""
+    network, initial = "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "ini_abund_waterice_loMetal.dat"
+    with tempfile.TemporaryDirectory() as td:
+        np.savetxt(os.path.join(td, "cells.txt"), np.array([make_cell(*CELLS[0])]), fmt="%.17e")
+        with open(os.path.join(td, "run.nml"), "w") as f:
+            f.write("&ref_run\n chem_dir='%s'\n network='%s'\n initial='%s'\n out_dir='%s'\n cell_file='%s'\n ncell=1\n dump_jac=0\n solve=0\n"
+                    " dump_iter_file=1\n/\n" % (INP, network, initial, td, os.path.join(td, "cells.txt")))
+        subprocess.run([DRIVER, os.path.join(td, "run.nml")], stdout=subprocess.DEVNULL, check=True)
+        txt = open(os.path.join(td, "iter_probe.dat")).read()
+    open(os.path.join(HERE, "iter_probe_grain.dat"), "w").write(txt)
+    print("wrote iter_probe_grain.dat", len(txt), "bytes")
+
+
 def main_shielding():
     """tests/golden/shielding.npz: the reference's self-shielding functions (oracle/_ref/ref_shielding) at seeded points.
     H2: 256 points.  CO: the function sampled on a coarse node grid of OURS (the table the product helper is then given) and at
@@ -424,6 +439,8 @@ if __name__ == "__main__":
         main_grid64()
     elif len(sys.argv) > 1 and sys.argv[1] == "evolT":
         main_evolT()
+    elif len(sys.argv) > 1 and sys.argv[1] == "iterprobe":
+        main_iterprobe()
     else:
         main()
         main_policy()

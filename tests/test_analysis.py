@@ -6,6 +6,8 @@ import io
 
 import numpy as np
 
+import os
+import pytest
 from conftest import DATA, GOLDEN
 
 G = np.load(f"{GOLDEN}/policy_grain.npz")
@@ -76,3 +78,27 @@ def test_snapshot_blocks_are_written(racgpu):
     racgpu.analysis.write_contributions(f, net, 1e6, y, G["ana_rates"], G["policy_cells"][0], [net.species_index("CO"), net.species_index("H2O")])
     txt = f.getvalue()
     assert "Total net charge" in txt and "Production" in txt and "Destruction" in txt and "CO  " in txt
+
+
+def test_iter_dat_writer_reproduces_the_references_file(racgpu):
+    """analysis.write_iter_dat against the reference's own writer (tests/golden/iter_probe_grain.dat: write_header +
+    disk_save_results_write on a cell whose k-th printed field holds k + k/1000, abundance i = i * 1e-3), byte for byte; and the file
+    reads back under the parsing rules of the reference's reader (first line without its first character split on blanks = keys,
+    numpy.loadtxt(comments='!') columns = values)."""
+    A = racgpu.analysis
+    net = racgpu.Network(os.path.join(DATA, "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat"))
+    ref = open(os.path.join(GOLDEN, "iter_probe_grain.dat")).read().splitlines()
+    cols = {}
+    for k, name in enumerate(A.ITER_INT_COLUMNS + A.ITER_REAL_COLUMNS, start=1):
+        cols[name] = np.array([float(k) if k <= 6 else k + k * 1e-3])
+    cols["cvg"] = np.array([1.0]); cols["cr_count"] = np.array([0.0])  # (converged = .true.; no optical record: cr_count prints 0)
+    y = (np.arange(1, net.nSpecies + 1) * 1e-3)[None, :]
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, "iter_0001.dat")
+        A.write_iter_dat(fn, net.names, cols, y)
+        mine = open(fn).read().splitlines()
+        d = A.load_iter_dat(fn)
+    assert mine[0].rstrip() == ref[0].rstrip()
+    assert mine[1] == ref[1]
+    assert len(d) == 148 + net.nSpecies and d["w_Kep"][0] == pytest.approx(142.142) and d["gH2O"][0] == pytest.approx((net.names.index("gH2O") + 1) * 1e-3)
