@@ -14,7 +14,7 @@ from conftest import DATA, GOLDEN_TAGS, ROOT, load_golden
 def test_abi_exports_every_declared_symbol(racgpu):
     lib = racgpu.lib()
     hdr = open(os.path.join(ROOT, "include", "racgpu.h")).read()
-    declared = set(re.findall(r"\b(racgpu_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(racgpu_[A-Za-z0-9_]+)\s*\(", hdr))
     assert declared == set(racgpu.ABI_SYMBOLS), declared ^ set(racgpu.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
