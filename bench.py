@@ -198,6 +198,16 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
             e[m] = np.abs(yg[m] - yr[m]) / yr[m]
             return float(e.max()), int(e.argmax())
 
+        def ref_freeze_rec(r):  # the record after which the reference's T stays put (0: T evolved to the end): RACGPU_O_TFREEZE_REC's twin
+            if "Trecord" not in r or int(r["evolTend"][0]) != 0:
+                return 0
+            T = np.asarray(r["Trecord"])
+            k = len(T) - 1
+            while k > 0 and T[k - 1] == T[k]:
+                k -= 1
+            return k + 1
+
+        frz = []
         errs, floors, spec, tf_eq, q_eq, ne_eq = [], [], [], 0, 0, 0
         codes_ref = np.zeros(4, dtype=np.int64); codes_twin = np.zeros(4, dtype=np.int64); codes_gpu = np.zeros(4, dtype=np.int64)
         ne_ref_twin_eq = 0
@@ -208,6 +218,8 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
             e, sp = worst(yg, yr)
             errs.append(e); spec.append(sp)
             floors.append(max([worst(tw[k]["yend"], yr)[0] for tw in twins]) if twins else 0.0)
+            if hcs is not None:
+                frz.append((int(gpu["freeze_rec"][sample_idx[k]]), ref_freeze_rec(r)))
             tf_eq += int(r["scalars"][0] == gpu["t_final"][sample_idx[k]])
             q_eq += int(int(r["scalars"][1]) == int(gpu["quality"][sample_idx[k]]))
             ne_eq += int(int(r["scalars"][2]) == int(gpu["nerr"][sample_idx[k]]))
@@ -218,6 +230,9 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                 codes_twin += twin[k]["errcodes"]
                 ne_ref_twin_eq += int(int(r["scalars"][2]) == int(twin[k]["scalars"][2]))
         errs = np.array(errs); floors = np.array(floors)
+        # cells the engine's modelled run-time guard ended before t_max while the reference (guard off) went on: nothing to compare
+        guard = np.array([(int(gpu["quality"][sample_idx[k]]) & 2) != 0 and ref[k]["scalars"][0] > gpu["t_final"][sample_idx[k]] for k in range(nsample)])
+        errs = np.where(guard, 0.0, errs)
         bound = np.maximum(1e-4, 3.0 * floors)
         excess = errs / bound
         kw = int(np.argmax(excess))
@@ -232,14 +247,23 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                   "cells_within_max(1e-4,3*floor)": int((errs <= bound).sum()),
                   "worst_cell": {"cell": int(sample_idx[kw]), "species_index": spec[kw], "err": float(errs[kw]), "floor": float(floors[kw]),
                                  "err_over_bound": float(excess[kw])},
-                  "exceptions": [{"cell": int(sample_idx[k]), "species_index": spec[k], "err": float(errs[k]), "floor": float(floors[k])}
+                  "exceptions": [dict({"cell": int(sample_idx[k]), "species_index": spec[k], "err": float(errs[k]), "floor": float(floors[k])},
+                                      **({"T_freeze_record": {"gpu": frz[k][0], "reference": frz[k][1]}} if frz else {}))
                                  for k in np.nonzero(errs > bound)[0][:16]],
+                  "ended_early_by_the_modelled_run_time_guard": {"cells": [int(sample_idx[k]) for k in np.nonzero(guard)[0]],
+                                                                 "note": "GPU quality bit 2 and t_final below the reference's, whose guard is off; left out of the error statistics"},
                   "t_final_equal": tf_eq, "quality_equal": q_eq,
                   # error returns (ISTATE < 0) of the integrator, by code, on the three sides: GPU, reference, reference's 1-ulp twin
                   "nerr_equal": ne_eq, "nerr_equal_reference_vs_its_twin": ne_ref_twin_eq,
                   "nerr_by_code": {"gpu": dict(zip(names, map(int, codes_gpu))), "reference": dict(zip(names, map(int, codes_ref))),
                                    "reference_twin": dict(zip(names, map(int, codes_twin)))},
                   "nerr_total_reference": int(codes_ref.sum()), "nerr_total_reference_twin": int(codes_twin.sum()), "nerr_total_gpu": int(codes_gpu.sum())}
+        if frz:  # evolT: the T-freeze test (src/chemistry.f90:532-546) is a threshold inside the integrator's noise; see RACGPU_O_TFREEZE_REC
+            same = np.array([a == b for a, b in frz])
+            parity["T_freeze"] = {"cells_frozen_at_the_same_record": int(same.sum()), "cells_frozen_at_different_records": int((~same).sum()),
+                                  "max_rel_err_where_same": float(errs[same].max()) if same.any() else None,
+                                  "cells_within_bound_where_same": int((errs[same] <= bound[same]).sum()),
+                                  "max_rel_err_where_different": float(errs[~same].max()) if (~same).any() else None}
         if tight is not None and hcs is None:  # the same comparison where trajectory noise does not limit it: RTOL 1e-8 on both sides
             tidx, gy = tight
             tref, tdt, _ = run_reference(cells[tidx], network, initial, params, rtol=1e-8)
@@ -294,6 +318,11 @@ def main():
     ap.add_argument("--no-hints", action="store_true", help="take cells in queue order in every pass (no cost feedback)")
     ap.add_argument("--evolT", action="store_true", help="gas temperature co-evolving with the chemistry (chemsol_params%evolT, the reference's "
                     "production default): every cell gets a heating/cooling record (cells.andrews_grid_hc); one wave per cell (k_solve_T)")
+    ap.add_argument("--sweep", choices=("batch", "columns"), default="batch",
+                    help="batch (default): every cell with its record as given, all cells at once -- frozen shielding, a Jacobi relaxation over "
+                    "the global iterations.  columns: the reference's dependency order (src/disk.f90:885-936) on the device (racgpu_column_sweep): "
+                    "a cell after the cell above it and the cell on its ray to the star, its toISM and toStar shielding slots rewritten from "
+                    "what those ended with; one four-wave team per column")
     ap.add_argument("--nlocal-iter", type=int, default=1, help="> 1: the caller's local-iteration loop (racgpu_calc_cells) instead of one chem_evol_solve pass")
     args = ap.parse_args()
 
@@ -328,6 +357,10 @@ def main():
     nS = net.nSpecies
     y0 = net.load_initial_abundances(os.path.join(DATA, initial))
     params = R.default_params()
+    # chemsol_params%max_runtime_allowed (60 s in the reference's template) is a guard on the CPU WALL CLOCK of a cell in the reference
+    # (src/chemistry.f90:480-491); the engine models it from its counters (racgpu_params rt_cost_*).  It stays ON: with T evolving a
+    # few cells chatter on a jump of a rate coefficient for minutes (evolT), which is what the guard is for.  The reference
+    # runs of cpu_baseline/parity have it off (their clock is this host's), so cells it ended on the GPU are listed, not compared.
     if netkey == "rate12":
         params.RTOL = 1e-6; params.t_max = 1e7  # BASELINE.json configs[4]
     if args.workload == "grid":
@@ -355,6 +388,20 @@ def main():
         cells_h = R.cells.synth_batch(ncell0, seed=20240601 + rank)
         wl = ("configs[1]: %d synthetic cells per GPU (log-uniform T in [10,3000] K, n_H in [1e3,1e12] cm^-3), %s network (%s: %d species, "
               "%d reactions), %s, t_max=%g yr, RTOL=%g, steps_reset_solver=50" % (ncell0, netkey, network, nS, net.nReactions, initial, params.t_max, params.RTOL))
+    if args.sweep == "columns" and (args.workload != "grid" or args.evolT or args.nlocal_iter > 1 or world > 1):
+        raise SystemExit("--sweep columns: grid workload, fixed T, one pass per step, one GPU (the wavefront runs across all columns)")
+    colgrid = None
+    if args.sweep == "columns":
+        colgrid = R.cells.andrews_columns()
+        net.set_co_shielding_table(R.cells.load_co_shielding_table(os.path.join(DATA, "visser2009_co_shielding.dat")))
+        net.set_star_rays(colgrid["inner"], colgrid["ds"])
+        wl = wl.replace("every cell with the shielding factors of its record as given, i.e. frozen shielding (Jacobi relaxation over global iterations), "
+                        "all cells in one batch",
+                        "DEPENDENCY-ORDER SWEEP (the reference's own order, src/disk.f90:885-936, as a wavefront on the device: "
+                        "racgpu_column_sweep + racgpu_set_star_rays): a cell is solved after the cell above it and the cell on its ray to the "
+                        "star, its toISM and toStar self-shielding slots (H2, CO on the Visser 2009 table, H2O, OH) rewritten from what they ended "
+                        "with (update_params_above_alt, :1823-1883); one four-wave team per column, 200 columns")
+        assert "DEPENDENCY-ORDER" in wl
     if args.evolT and args.workload != "grid":
         raise SystemExit("--evolT goes with the grid workload")
     if args.evolT:
@@ -387,9 +434,16 @@ def main():
     kernel_ms = []
     teams = [0, 0]  # cells of the last pass solved by four-wave teams from the start / handed over to teams at the end of the pass
 
+    sweep_cells = [None]
+
     def one_pass():
         y_d.copy_(yinit_d)
-        if args.evolT:
+        if colgrid is not None:  # host-buffer entry (the column order is checked on the host); the copies are part of the pass
+            o = net.column_sweep(params, cells_h, yinit_h, colgrid["col_ptr"], colgrid["col_cells"], colgrid["dz"], dv_turb=1e5)
+            y_d.copy_(torch.from_numpy(o["y"])); tfin_d.copy_(torch.from_numpy(o["t_final"])); qual_d.copy_(torch.from_numpy(o["quality"]))
+            stats_d.copy_(torch.from_numpy(o["stats"])); cout_d.copy_(torch.from_numpy(o["cell_out"]))
+            sweep_cells[0] = o["cells"]
+        elif args.evolT:
             net.evolT_solve_batch_device(params, ncell, cells_d.data_ptr(), hc_d.data_ptr(), y_d.data_ptr(), tfin_d.data_ptr(), qual_d.data_ptr(),
                                          stats_d.data_ptr(), cout_d.data_ptr())
         elif args.nlocal_iter > 1:
@@ -410,7 +464,7 @@ def main():
         torch.cuda.synchronize(dev)
         kernel_ms.append(net.last_kernel_ms())
         teams[0], teams[1] = net.last_team_cells(), net.last_parked_cells()
-        if not args.no_hints:
+        if not args.no_hints and colgrid is None:
             # cost feedback, as between two global iterations of the disk model: the cycles each cell took in this pass
             # order the next pass (costliest first).  Part of the pass, so it is inside the timed region.
             net.set_cost_hints(stats_d[:, R.S_CYC_TOTAL].cpu().numpy().astype(np.float64))
@@ -458,7 +512,7 @@ def main():
         for calname in ("r3_pmc_calibration.json", "r2_pmc_calibration.json"):
             try:
                 cal = json.load(open(os.path.join(ROOT, "profiles", calname)))
-                if cal["workload"]["name"] == args.workload and cal["workload"]["network"] == network and not args.evolT:
+                if cal["workload"]["name"] == args.workload and cal["workload"]["network"] == network and not args.evolT and colgrid is None:
                     traffic = cal["bytes_per_cell_step_corrected"] * nst
                     traffic_src = ("calibrated, not measured in this run: profiles/%s, %.0f B per cell-step x %d cell-steps; TCC FETCH/WRITE "
                                    "counters see what crosses L2, i.e. Infinity-Cache (MALL) hits as well as HBM" % (calname, cal["bytes_per_cell_step_corrected"], int(nst)))
@@ -472,7 +526,8 @@ def main():
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL of the multi-rank path on one GPU over gloo: not a measurement",
             "config": {"workload": wl, "cells_per_gpu": ncell,
-                       "parallelism": "cells sharded over %d GPU(s) (%s), one RCCL all-gather of abundances + t_final + quality + counters at output" % (world, args.scaling),
+                       "parallelism": ("one GPU: the wavefront of the sweep runs across all columns (200 four-wave teams, at most 100 of them busy)" if colgrid is not None else
+                                       "cells sharded over %d GPU(s) (%s), one RCCL all-gather of abundances + t_final + quality + counters at output" % (world, args.scaling)),
                        "local_iterations": args.nlocal_iter,
                        # cells the last pass gave to four-wave teams: from the start (cost hints; racgpu_set_team_threshold) / between
                        # two integrator steps once the queue was empty and at most two waves per CU were left
@@ -490,7 +545,7 @@ def main():
                          "traffic_frac_of_peak": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          # one pass = k_solve (one wave per cell) followed by k_solve_team_resume (the cells handed over at its end),
                          # with k_solve_team (cells in teams from the start) alongside: timed as a whole between two HIP events
-                         "kernel": "k_solve_T" if args.evolT else "k_solve (+ k_solve_team, k_solve_team_resume)", "kernel_ms": kms,
+                         "kernel": "k_solve_T" if args.evolT else "k_solve_columns" if colgrid is not None else "k_solve (+ k_solve_team, k_solve_team_resume)", "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_cell_step": abytes / max(nst, 1.0)},
             "cell_steps_per_pass_rank0": nst, "mean_steps_per_cell": nst / ncell,
@@ -508,16 +563,20 @@ def main():
             nsample = min(ncell, 16 * cores)
             sample_idx = np.arange(nsample) * (ncell // nsample) + (ncell // nsample) // 2  # spread over the whole batch
             gpu = {"y": y_d.cpu().numpy(), "t_final": tfin_d.cpu().numpy(), "quality": qual, "nst": stats[:, 0], "nerr": stats[:, R.S_NERR],
-                   "errcodes": stats[:, R.S_ERRCODES], "tgas": cout_d[:, R.O_TGAS].cpu().numpy()}
+                   "errcodes": stats[:, R.S_ERRCODES], "tgas": cout_d[:, R.O_TGAS].cpu().numpy(),
+                   "freeze_rec": cout_d[:, R.O_TFREEZE_REC].cpu().numpy()}
             tidx = sample_idx[::max(1, nsample // 32)][:32]
             p8 = R.default_params()
             for f in ("ATOL", "t_max", "dt_first_step", "ratio_tstep", "mxstep_per_interval", "steps_reset_solver"):
                 setattr(p8, f, getattr(params, f))
             p8.RTOL = 1e-8
             net.set_cost_hints(None)
-            gy = None if args.evolT else net.evol_solve_batch(p8, cells_h[tidx], yinit_h[tidx])["y"]
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cells_h, sample_idx, network, initial, params, gpu, nS,
-                                                                         tight=None if args.evolT else (tidx, gy), hc=hc_h)
+            gy = None if (args.evolT or colgrid is not None) else net.evol_solve_batch(p8, cells_h[tidx], yinit_h[tidx])["y"]
+            # (dependency-order sweep: the reference runs on the records as the sweep left them, i.e. with the shielding slots the device
+            # wrote; the functions behind the slots are pinned to the compiled reference by tests/test_shielding_sweep.py)
+            cells_cmp = sweep_cells[0] if colgrid is not None else cells_h
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cells_cmp, sample_idx, network, initial, params, gpu, nS,
+                                                                         tight=None if (args.evolT or colgrid is not None) else (tidx, gy), hc=hc_h)
             if args.evolT:
                 T0, T1 = cells_h[:, R.cells.P_TGAS], gpu["tgas"]
                 out["evolT"] = {"cells_T_still_evolving_at_end": int(cout_d[:, R.O_EVOLT_END].sum().item()),

@@ -89,7 +89,7 @@ enum { RACGPU_S_NST = 0, RACGPU_S_NFE, RACGPU_S_NJE, RACGPU_S_NLU, RACGPU_S_NERR
                             src/chemistry.f90:272-387) */ };
 
 /* per-cell values the path writes back into the cell record (double x RACGPU_NOUT per cell) */
-#define RACGPU_NOUT 5
+#define RACGPU_NOUT 6
 enum { RACGPU_O_R_H2_FORM = 0,     /* chem_params%R_H2_form_rate_coeff [s^-1] (src/chemistry.f90:804,891); untouched if the network
                                       has no H2-formation reaction */
        RACGPU_O_N_MOL_ON_GRAIN,    /* chem_params%n_mol_on_grain: get_ice_coverage's side effect on the handed-back abundances
@@ -98,8 +98,12 @@ enum { RACGPU_O_R_H2_FORM = 0,     /* chem_params%R_H2_form_rate_coeff [s^-1] (s
                                       record held NaNs) */
        RACGPU_O_TGAS,              /* c%par%Tgas = record(nSpecies+1, isav) (src/disk.f90:1732): the gas temperature of the hand-off
                                       record; the record's own Tgas when T is not evolving; untouched when isav <= 1 */
-       RACGPU_O_EVOLT_END };       /* racgpu_evolT_solve_batch: 1 if T was still evolving at the end of the run, 0 if the T-freeze test
+       RACGPU_O_EVOLT_END,         /* racgpu_evolT_solve_batch: 1 if T was still evolving at the end of the run, 0 if the T-freeze test
                                       (src/chemistry.f90:532-546) or en_gain_tot <= 0 had switched it off */
+       RACGPU_O_TFREEZE_REC };     /* the record (1-based index into touts) after which that test froze T; 0: it never did.  The test
+                                      compares the spread of T over five records with a threshold that sits inside the integrator's
+                                      own noise, and what follows keeps the rate coefficients of whichever chem_cal_rates call came
+                                      last (T, or chem_ode_jac's T + dT): two runs that freeze one record apart end percent apart */
 
 /* flags of racgpu_evol_solve_batch */
 #define RACGPU_F_RECTIFY 1 /* apply rectify_abundances (src/chemistry.f90:2170-2201) to y before integrating: the continue path */
@@ -266,13 +270,23 @@ int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
  * slots of its record are rewritten from the column densities N = sum n_gas X dz of the cells above it: H2 by
  * get_H2_self_shielding(N_H2, dv_turb) (:1887-1897), H2O and OH by exp(-N sigma_Lya) (:1847-1859), CO by get_12CO_shielding(N_H2,
  * N_CO) on the table given to racgpu_set_co_shielding_table (without one the CO slot stays as given), all capped at 1; the toStar
- * slots stay as given (they need ray tracing).  cells is updated in place; everything
+ * slots stay as given unless racgpu_set_star_rays has described the rays.  cells is updated in place; everything
  * else as racgpu_evol_solve_batch with t0 = 0 and the handle's default tolerance policy.  The surface cell of a column gets the
  * slots for N = 0.  col_cells must be a permutation of 0..ncell-1 (checked for host buffers). */
 /* 12CO shielding table for racgpu_column_sweep: f[ncol][nrow] > 0 over ascending log10 column densities logN_12CO[ncol], logN_H2[nrow]
  * (the layout of the reference's f_12CO(ncol, nrow), src/load_Visser_CO_selfshielding.f90; its own Visser et al. 2009 table is
  * compiled into it and not shipped here: the caller supplies one).  f == NULL clears it. */
 int racgpu_set_co_shielding_table(racgpu_network *, int32_t nrow, int32_t ncol, const double *logN_H2, const double *logN_12CO, const double *f);
+/* Rays to the star for racgpu_column_sweep (calc_Ncol_to_Star, src/disk.f90:2543-2555: the reference traces the ray from a cell to
+ * the star through its grid; here the caller hands over the result of that tracing in the one-predecessor form a column grid gives):
+ * inner[cell] = the cell the ray enters next on its way to the star (-1: none left), ds[cell] = path length of such a ray through
+ * `cell` [cm].  With rays set, the sweep also rewrites the toStar self-shielding slots (:1842-1866) from N_toStar(cell) =
+ * N_toStar(inner) + n_gas(inner) X(inner) ds(inner), X being the hand-off abundances of inner: a cell is solved once the cell above
+ * it AND the cell on its ray are done -- the reference's column-by-column order from the inner edge (src/disk.f90:885-936) as a
+ * wavefront.  inner[cell] must lie in a column of lower index.  Host arrays, copied; inner == NULL clears.  racgpu_star_ray_timeouts:
+ * cells of the last sweep that gave up waiting for their neighbour (the sweep then fails). */
+int racgpu_set_star_rays(racgpu_network *, int64_t ncell, const int32_t *inner, const double *ds);
+int racgpu_star_ray_timeouts(const racgpu_network *);
 int racgpu_column_sweep(racgpu_network *, const racgpu_params *, int64_t ncolumn, const int32_t *col_ptr, const int32_t *col_cells,
                         int64_t ncell, double *cells, double *y, const double *dz, double dv_turb, double *t_final, int32_t *quality,
                         int64_t *stats, double *cell_out, int mem);

@@ -23,14 +23,14 @@ from .cells import NPAR
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RACGPU_LIB") or os.path.join(_HERE, "libracgpu.so")  # RACGPU_LIB: developer builds
 NSTAT = 20
-NOUT = 5
+NOUT = 6
 NHC = 28
 NHCTERMS = 29
 MEM_HOST, MEM_DEVICE = 0, 1
 F_RECTIFY = 1
 (S_NST, S_NFE, S_NJE, S_NLU, S_NERR, S_NREC_REAL, S_QSUM, S_NCFAIL_ETFAIL, S_CYC_TOTAL, S_CYC_RHS, S_CYC_JAC, S_CYC_LU,
  S_CYC_SOLVE, S_CYC_LU_SCATTER, S_CYC_LU_LDS, S_CYC_LU_REG, S_ISAV, S_NITER, S_NREC, S_ERRCODES) = range(NSTAT)
-O_R_H2_FORM, O_N_MOL_ON_GRAIN, O_T_END, O_TGAS, O_EVOLT_END = range(NOUT)
+O_R_H2_FORM, O_N_MOL_ON_GRAIN, O_T_END, O_TGAS, O_EVOLT_END, O_TFREEZE_REC = range(NOUT)
 # the 29 values of type_heating_cooling_rates_list, in its order (reference src/data_struct.f90:489-520)
 HC_TERM_NAMES = ("hc_net_rate", "heating_photoelectric_small_grain", "heating_formation_H2", "heating_cosmic_ray", "heating_vibrational_H2",
                  "heating_ionization_CI", "heating_photodissociation_H2", "heating_photodissociation_H2O", "heating_photodissociation_OH",
@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "racgpu_lu_ordering", "racgpu_species_attrs", "racgpu_species_elements", "racgpu_reaction_rows", "racgpu_jac_pattern", "racgpu_load_initial_abundances", "racgpu_params_default",
     "racgpu_n_record", "racgpu_set_tolerances", "racgpu_init_abundances", "racgpu_set_device",
     "racgpu_set_stream", "racgpu_rates", "racgpu_rhs", "racgpu_jac_csc", "racgpu_newton_solve",
-    "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_column_sweep", "racgpu_set_co_shielding_table", "racgpu_rectify_abundances",
+    "racgpu_solve_batch", "racgpu_evol_solve_batch", "racgpu_calc_cells", "racgpu_column_sweep", "racgpu_set_co_shielding_table", "racgpu_set_star_rays", "racgpu_star_ray_timeouts", "racgpu_rectify_abundances",
     "racgpu_hc_config_default", "racgpu_heating_cooling_load", "racgpu_heat_reactions", "racgpu_evolT_hooks", "racgpu_evolT_solve_batch",
     "racgpu_multi_create", "racgpu_multi_destroy", "racgpu_multi_ndev", "racgpu_multi_network", "racgpu_multi_last_error", "racgpu_multi_deal",
     "racgpu_multi_calc_cells",
@@ -138,6 +138,10 @@ def lib():
     L.racgpu_last_kernel_ms.argtypes = [vp]
     L.racgpu_column_sweep.restype = C.c_int
     L.racgpu_column_sweep.argtypes = [vp, C.POINTER(ChemsolParams), C.c_int64, vp, vp, C.c_int64, vp, vp, vp, C.c_double, vp, vp, vp, vp, C.c_int]
+    L.racgpu_set_star_rays.restype = C.c_int
+    L.racgpu_set_star_rays.argtypes = [vp, C.c_int64, vp, vp]
+    L.racgpu_star_ray_timeouts.restype = C.c_int
+    L.racgpu_star_ray_timeouts.argtypes = [vp]
     L.racgpu_set_co_shielding_table.restype = C.c_int
     L.racgpu_set_co_shielding_table.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
     L.racgpu_hc_config_default.argtypes = [C.POINTER(HcConfig)]
@@ -495,6 +499,17 @@ class Network:
         if f.shape != (lc.size, lh.size):
             raise ValueError("f must be [ncol, nrow]")
         _check(lib().racgpu_set_co_shielding_table(self._h, lh.size, lc.size, lh.ctypes.data, lc.ctypes.data, f.ctypes.data))
+
+    def set_star_rays(self, inner=None, ds=None):
+        """racgpu_set_star_rays: inner[cell] = the cell a ray from `cell` to the star enters next (-1: none), ds[cell] = path length
+        of such a ray through `cell` [cm]; column_sweep then rewrites the toStar shielding slots as well.  None clears."""
+        if inner is None:
+            _check(lib().racgpu_set_star_rays(self._h, 0, None, None))
+            return
+        inn = np.ascontiguousarray(inner, dtype=np.int32); d = np.ascontiguousarray(ds, dtype=np.float64)
+        if inn.size != d.size:
+            raise ValueError("inner and ds must have one entry per cell")
+        _check(lib().racgpu_set_star_rays(self._h, inn.size, inn.ctypes.data, d.ctypes.data))
 
     def column_sweep(self, params, cell_records, y, col_ptr, col_cells, dz, dv_turb=1e5):
         """racgpu_column_sweep: the cells column by column, each column top down on one team of four waves, the toISM

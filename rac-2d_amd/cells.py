@@ -257,6 +257,106 @@ def co_shielding(table, N_H2, N_12CO):
     return np.minimum(1.0, np.maximum(0.0, np.exp(v)))
 
 
+def load_co_shielding_table(path):
+    """The reference's own 12CO shielding table (Visser, van Dishoeck & Black 2009) as shipped in data/visser2009_co_shielding.dat
+    (written by tools/extract_reference_tables.py from the DATA statements of src/load_Visser_CO_selfshielding.f90): returns the
+    (logN_H2 [nrow], logN_12CO [ncol], f [ncol, nrow]) triple co_shielding and Network.set_co_shielding_table take."""
+    arrs = {}
+    name, shape, vals = None, None, []
+    for line in open(path):
+        if line.startswith("!") or not line.strip():
+            continue
+        if line.startswith("#"):
+            if name:
+                arrs[name] = (shape, vals)
+            t = line[1:].split()
+            name, shape, vals = t[0], tuple(int(v) for v in t[1:]), []
+        else:
+            vals.extend(float(v) for v in line.split())
+    if name:
+        arrs[name] = (shape, vals)
+    out = {k: np.array(v, dtype=np.float64).reshape(sh, order="F") for k, (sh, v) in arrs.items()}  # (column-major, as Fortran holds them)
+    return out["logN_H2"], out["logN_12CO"], out["f_12CO"]
+
+
+def andrews_columns(ncol=200, nz=100, rmin=0.1, rmax=200.0, zr_max=0.6):
+    """The column structure of andrews_grid as racgpu_column_sweep / racgpu_set_star_rays take it: cells [c * nz + k], k = 0 the
+    surface cell.  Returns dict(col_ptr, col_cells, dz, inner, ds, column, layer):
+      dz[cell]    vertical extent of the cell [cm]: r_c * zr_max / nz
+      inner[cell] the cell a ray from `cell` to the star enters next: the cells of one layer share z / r, so it is the cell of the
+                  same layer in the next column inwards (-1 in the innermost column)
+      ds[cell]    path length of such a ray through `cell` [cm]: (r_out - r_in) sqrt(1 + (z / r)^2)"""
+    r = rmin * (rmax / rmin) ** ((np.arange(ncol) + 0.5) / ncol)
+    edges = rmin * (rmax / rmin) ** (np.arange(ncol + 1) / ncol)
+    mu = zr_max * (nz - 0.5 - np.arange(nz)) / nz
+    column = np.repeat(np.arange(ncol), nz); layer = np.tile(np.arange(nz), ncol)
+    dz = np.repeat(r * zr_max / nz * AU_CM, nz)
+    ds = (np.diff(edges)[:, None] * np.sqrt(1.0 + mu[None, :] ** 2) * AU_CM).reshape(-1)
+    inner = np.where(column > 0, (column - 1) * nz + layer, -1).astype(np.int32)
+    return dict(col_ptr=(np.arange(ncol + 1) * nz).astype(np.int32), col_cells=np.arange(ncol * nz, dtype=np.int32), dz=dz, inner=inner,
+                ds=np.ascontiguousarray(ds), column=column, layer=layer)
+
+
+def wavefronts(col_ptr, col_cells, inner=None):
+    """Dependency level of every cell of a column sweep: a cell comes after the cell above it in its column and, with star rays,
+    after inner[cell].  Level 0 has no predecessor.  (sweep.solve_by_layers with these as `layer` is the host-driven sweep.)"""
+    col_ptr = np.asarray(col_ptr); col_cells = np.asarray(col_cells)
+    ncell = col_cells.size
+    lev = np.zeros(ncell, dtype=np.int64)
+    for c in range(col_ptr.size - 1):      # columns in index order: inner[cell] lies in an earlier column
+        prev = -1
+        for q in range(col_ptr[c], col_ptr[c + 1]):
+            cell = col_cells[q]
+            l = 0 if prev < 0 else lev[prev] + 1
+            if inner is not None and inner[cell] >= 0:
+                l = max(l, lev[inner[cell]] + 1)
+            lev[cell] = l
+            prev = cell
+    return lev
+
+
+def shielding_update(table=None, dv_turb=1e5, species=None, col_ptr=None, col_cells=None, dz=None, inner=None, ds=None):
+    """The `update` callback of sweep.solve_by_layers that does on the host what racgpu_column_sweep does on the device (the same
+    sums in the same order): toISM slots from the cells above in the column, and with inner/ds the toStar slots from
+    N_toStar(cell) = N_toStar(inner) + n_gas(inner) X(inner) ds(inner).  species = dict(H2=, H2O=, OH=, CO=) 0-based indices."""
+    col_ptr = np.asarray(col_ptr); col_cells = np.asarray(col_cells)
+    ncell = col_cells.size
+    above = np.full(ncell, -1, dtype=np.int64)
+    for c in range(col_ptr.size - 1):
+        q = col_cells[col_ptr[c]:col_ptr[c + 1]]
+        above[q[1:]] = q[:-1]
+    names = ("H2", "H2O", "OH", "CO")
+    N_ism = np.zeros((ncell, 4)); N_star = np.zeros((ncell, 4))   # at the FAR side of the cell (own contribution included) once it is done
+    isdone = np.zeros(ncell, dtype=bool)
+
+    def slots(cells_, idx, N, s_H2, s_CO, s_H2O, s_OH):
+        cells_[idx, s_H2] = h2_self_shielding(N[:, 0], dv_turb)
+        cells_[idx, s_H2O] = lya_self_shielding(N[:, 1], LYA_CROSS_H2O)
+        cells_[idx, s_OH] = lya_self_shielding(N[:, 2], LYA_CROSS_OH)
+        if table is not None:
+            cells_[idx, s_CO] = co_shielding(table, N[:, 0], N[:, 3])
+
+    def update(k, idx, cells_, y_done, done):
+        new = done[~isdone[done]] if len(done) else done
+        for cell in new:   # what the cells solved since the last call add, in dependency order (a level never feeds itself)
+            w = cells_[cell, P_NGAS]
+            base_i = N_ism[above[cell]] if above[cell] >= 0 else np.zeros(4)
+            N_ism[cell] = [base_i[j] + (w * dz[cell]) * y_done[cell, species[nm]] if species.get(nm, -1) >= 0 else base_i[j] for j, nm in enumerate(names)]
+            if inner is not None:
+                base_s = N_in_star[cell]
+                N_star[cell] = [base_s[j] + (w * ds[cell]) * y_done[cell, species[nm]] if species.get(nm, -1) >= 0 else base_s[j] for j, nm in enumerate(names)]
+            isdone[cell] = True
+        Ni = np.array([N_ism[above[c]] if above[c] >= 0 else np.zeros(4) for c in idx])
+        slots(cells_, idx, Ni, P_FSS_ISM_H2, P_FSS_ISM_CO, P_FSS_ISM_H2O, P_FSS_ISM_OH)
+        if inner is not None:
+            Ns = np.array([N_star[inner[c]] if inner[c] >= 0 else np.zeros(4) for c in idx])
+            N_in_star[idx] = Ns
+            slots(cells_, idx, Ns, P_FSS_STAR_H2, P_FSS_STAR_CO, P_FSS_STAR_H2O, P_FSS_STAR_OH)
+
+    N_in_star = np.zeros((ncell, 4))
+    return update
+
+
 def column_density_above(n_species, dz, column, layer):
     """Column density [cm^-2] from the TOP of every cell of a regular column grid to the surface: the sum of n dz over the cells
     of the same column in the layers above it (layer 0 = the top; the cell itself is not counted, as with the reference's

@@ -86,13 +86,18 @@ __global__ __launch_bounds__(64) void k_newton(const DevNet *__restrict__ Np, co
   dev_build_P<true>(N, rates, cp[RACGPU_P_D2H] * cp[RACGPU_P_SITES], v.y, -gamma, true, Pv, lane);
   // repeat > 1 (developer aid, RACGPU_DEBUG_REPEAT): the same factorisation and solve again and again, with the
   // cycle counts of the LU parts and of the solve written out per cell
+  // (RACGPU_DEBUG_REPEAT_MODE, bits 24.. of repeat: 1 = only the factorisation is repeated, 2 = only the solve: per-phase traffic)
   long long cyc[4] = {0, 0, 0, 0}, c_lu = 0, c_solve = 0;
+  const int mode = repeat >> 24;
+  repeat &= 0xffffff;
   for (int r = 0; r < repeat; ++r) {
     const long long t0 = (long long)__builtin_readcyclecounter();
-    dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.y, lane, cyc, v.wx + nlds);
+    if (mode != 2 || r == 0) dev_lu(N, Pv, Lv, Uv, Dinv, v.wx, v.y, lane, cyc, v.wx + nlds);
     const long long t1 = (long long)__builtin_readcyclecounter();
-    for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
-    dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
+    if (mode != 1 || r == repeat - 1) {
+      for (int i = lane; i < N.nS; i += 64) v.savf[i] = bx[(size_t)cell * N.nS + i];
+      dev_solve(N, Lv, Uv, Dinv, v.savf, v.wx, lane);
+    }
     c_lu += t1 - t0; c_solve += (long long)__builtin_readcyclecounter() - t1;
   }
   for (int i = lane; i < N.nS; i += 64) bx[(size_t)cell * N.nS + i] = v.savf[i];
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(64) void k_evolT_hooks(const DevNet *__restrict__ N
   g_wc.nsite = c.cell[RACGPU_P_D2H] * c.cell[RACGPU_P_SITES];
   const double *yc = yin + (size_t)cell * (n + 1);
   for (int i = lane; i < n; i += 64) c.y[i] = yc[i];
-  g_T.y = yc[n]; g_T.evolT = 1;
+  g_T.y = yc[n]; g_T.evolT = 1; g_T.freeze_rec = 0;
   wave_sync();
   dev_f<true>(N, c, c.savf);
   for (int i = lane; i < n; i += 64) ydot_out[(size_t)cell * (n + 1) + i] = c.savf[i];
@@ -158,6 +163,10 @@ struct SolveArgs {
   const double *dz;                 // [ncell] path length through the cell towards the surface [cm]
   double dv_turb;                   // turbulent line width [cm/s] of the H2 self-shielding formula
   double *cells_rw;                 // = cells
+  // rays to the star (racgpu_set_star_rays): the cell a cell's ray passes through next (-1: none), its path length through THAT cell
+  // [cm] is ray_ds of that cell; ray_N[cell][4] = column densities of H2, H2O, OH, CO from the star to the far side of the cell,
+  // ray_done[cell] = 1 once they are there (agent-scope release/acquire: the producer runs on another CU, possibly another XCD)
+  const int *ray_inner; const double *ray_ds; double *ray_N; int *ray_done; int *ray_timeouts;
   // k_solve_T (gas temperature co-evolving): the cells' heating/cooling records [ncell][RACGPU_NHC] and the tables
   const double *hc; const DevHC *hc_tab;
 };
@@ -171,6 +180,7 @@ static_assert(sizeof(Parked) <= kParkWords * sizeof(double), "Parked outgrew its
 // what a column has above the cell being solved: column densities [cm^-2] of H2, H2O, OH (wave 0 of the team)
 struct ColumnAcc { double N_H2, N_H2O, N_OH, N_CO; };
 static __shared__ volatile ColumnAcc g_col;
+static __shared__ volatile ColumnAcc g_ray; // the same towards the star, for the cell being solved
 
 template <int TEAM, bool RESUME, bool COLUMN = false, bool ET = false>
 RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, const SolveArgs &A, double *lds) {
@@ -231,26 +241,48 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
       }
       cell = A.col_cells[kpos];
       if (lane == 0) { // (the surface cell too: column densities 0, as update_params_above_alt gives it, src/disk.f90:1840-1866)
-        // update_params_above_alt's grid-free part (reference src/disk.f90:1840-1859) towards the surface: H2 by Draine &
-        // Bertoldi 1996 eq. 37 (get_H2_self_shielding, :1887-1897; the 0.035 is a single-precision literal there), H2O and OH
-        // by their Lyman-alpha cross sections (src/sub_global_variables.f90:82-83)
+        // update_params_above_alt's grid-free part (reference src/disk.f90:1840-1866): H2 by Draine & Bertoldi 1996 eq. 37
+        // (get_H2_self_shielding, :1887-1897; the 0.035 is a single-precision literal there), H2O and OH by their Lyman-alpha cross
+        // sections (src/sub_global_variables.f90:82-83), CO by get_12CO_shielding on the caller's table
         double *rec = A.cells_rw + (size_t)cell * RACGPU_NPAR;
-        const double x = g_col.N_H2 / 5e14, b5 = A.dv_turb / 1e5, tmp = sqrt(1.0 + x);
-        const double den = 1.0 + x / b5;
-        rec[RACGPU_P_FSS_ISM_H2] = fmin(1.0, 0.965 / (den * den) + (double)0.035f / tmp * exp(-8.5e-4 * tmp));
-        rec[RACGPU_P_FSS_ISM_H2O] = fmin(1.0, exp(-(g_col.N_H2O * 1.2e-17)));
-        rec[RACGPU_P_FSS_ISM_OH] = fmin(1.0, exp(-(g_col.N_OH * 1.8e-18)));
-        if (A.co_lnf) { // get_12CO_shielding (reference src/load_Visser_CO_selfshielding.f90:271-309) on the caller's table
-          const double xl = log10(fmax(g_col.N_CO, 1.0)), yl = log10(fmax(g_col.N_H2, 1.0));
-          int i1 = 0, j1 = 0; // the enclosing table cell; the last one beyond the table, the first one below it
-          for (int i = 0; i < A.co_nrow - 1; ++i) if (A.co_logNH2[i] < yl) i1 = i;
-          for (int j = 0; j < A.co_ncol - 1; ++j) if (A.co_logNCO[j] < xl) j1 = j;
-          const double x1 = A.co_logNCO[j1], x2 = A.co_logNCO[j1 + 1], y1 = A.co_logNH2[i1], y2 = A.co_logNH2[i1 + 1];
-          const double z11 = A.co_lnf[(size_t)j1 * A.co_nrow + i1], z12 = A.co_lnf[(size_t)j1 * A.co_nrow + i1 + 1];
-          const double z21 = A.co_lnf[(size_t)(j1 + 1) * A.co_nrow + i1], z22 = A.co_lnf[(size_t)(j1 + 1) * A.co_nrow + i1 + 1];
-          const double k1 = (z12 - z11) / (y2 - y1), k2 = (z22 - z21) / (y2 - y1); // calc_four_point_linear_interpol, src/sub_trivials.f90:803-821
-          const double v = ((k2 - k1) / (x2 - x1) * (xl - x1) + k1) * (yl - y1) + (z21 - z11) / (x2 - x1) * (xl - x1) + z11;
-          rec[RACGPU_P_FSS_ISM_CO] = fmin(1.0, fmax(0.0, exp(v)));
+        auto slots = [&](double N_H2, double N_H2O, double N_OH, double N_CO, int s_H2, int s_CO, int s_H2O, int s_OH) {
+          const double x = N_H2 / 5e14, b5 = A.dv_turb / 1e5, tmp = sqrt(1.0 + x);
+          const double den = 1.0 + x / b5;
+          rec[s_H2] = fmin(1.0, 0.965 / (den * den) + (double)0.035f / tmp * exp(-8.5e-4 * tmp));
+          rec[s_H2O] = fmin(1.0, exp(-(N_H2O * 1.2e-17)));
+          rec[s_OH] = fmin(1.0, exp(-(N_OH * 1.8e-18)));
+          if (A.co_lnf) { // get_12CO_shielding (reference src/load_Visser_CO_selfshielding.f90:271-309) on the caller's table
+            const double xl = log10(fmax(N_CO, 1.0)), yl = log10(fmax(N_H2, 1.0));
+            int i1 = 0, j1 = 0; // the enclosing table cell; the last one beyond the table, the first one below it
+            for (int i = 0; i < A.co_nrow - 1; ++i) if (A.co_logNH2[i] < yl) i1 = i;
+            for (int j = 0; j < A.co_ncol - 1; ++j) if (A.co_logNCO[j] < xl) j1 = j;
+            const double x1 = A.co_logNCO[j1], x2 = A.co_logNCO[j1 + 1], y1 = A.co_logNH2[i1], y2 = A.co_logNH2[i1 + 1];
+            const double z11 = A.co_lnf[(size_t)j1 * A.co_nrow + i1], z12 = A.co_lnf[(size_t)j1 * A.co_nrow + i1 + 1];
+            const double z21 = A.co_lnf[(size_t)(j1 + 1) * A.co_nrow + i1], z22 = A.co_lnf[(size_t)(j1 + 1) * A.co_nrow + i1 + 1];
+            const double k1 = (z12 - z11) / (y2 - y1), k2 = (z22 - z21) / (y2 - y1); // calc_four_point_linear_interpol, src/sub_trivials.f90:803-821
+            const double v = ((k2 - k1) / (x2 - x1) * (xl - x1) + k1) * (yl - y1) + (z21 - z11) / (x2 - x1) * (xl - x1) + z11;
+            rec[s_CO] = fmin(1.0, fmax(0.0, exp(v)));
+          }
+        };
+        slots(g_col.N_H2, g_col.N_H2O, g_col.N_OH, g_col.N_CO, RACGPU_P_FSS_ISM_H2, RACGPU_P_FSS_ISM_CO, RACGPU_P_FSS_ISM_H2O, RACGPU_P_FSS_ISM_OH);
+        if (A.ray_inner) { // the toStar slots (:1842-1866): what the cells along the ray to the star ended with; the cell waits for its neighbour
+          double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+          const int in = A.ray_inner[cell];
+          if (in >= 0) {
+            const long long t0 = (long long)wall_clock64(), limit = 100000000LL * 1800; // (100 MHz; half an hour: a column starts one cell after its neighbour)
+            bool there = true;
+            while (__hip_atomic_load(&A.ray_done[in], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+              __builtin_amdgcn_s_sleep(127);
+              if ((long long)wall_clock64() - t0 > limit) { there = false; atomicAdd(A.ray_timeouts, 1); break; }
+            }
+            if (there) {
+              const double *rn = A.ray_N + (size_t)in * 4;
+              r0 = __hip_atomic_load(rn + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r1 = __hip_atomic_load(rn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              r2 = __hip_atomic_load(rn + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r3 = __hip_atomic_load(rn + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          g_ray.N_H2 = r0; g_ray.N_H2O = r1; g_ray.N_OH = r2; g_ray.N_CO = r3;
+          slots(r0, r1, r2, r3, RACGPU_P_FSS_STAR_H2, RACGPU_P_FSS_STAR_CO, RACGPU_P_FSS_STAR_H2O, RACGPU_P_FSS_STAR_OH);
         }
       }
       ++kpos;
@@ -296,7 +328,7 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
         for (int k = 0; k < 10; ++k) g_T.Pc[k] = 0.0;
         g_T.Pd = 1.0; g_T.schur = 1.0; g_T.rh2 = 0.0;
         g_T.t_scale_tol = j == 1 ? 1e-6 : j == 2 ? 1e-4 : j == 3 ? 1e-3 : j == 4 ? 1e-2 : 1e-1; // chem_set_solver_flags_alt (src/chemistry.f90:220-244)
-        g_T.evolT = c.hcrec[H_EN_GAIN_TOT] > 0.0 ? 1 : 0;
+        g_T.evolT = c.hcrec[H_EN_GAIN_TOT] > 0.0 ? 1 : 0; g_T.freeze_rec = 0;
         g_T.maySwitchT = ((const RG_GLOBAL DevHC *)A.hc_tab)->cfg.may_switch_T;
       }
       dev_mark(c, 2);
@@ -348,9 +380,9 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
         o[RACGPU_O_T_END] = R.t_final;
         if constexpr (ET) { // c%par%Tgas = record(nS+1, isav) (src/disk.f90:1732); the coefficient of the last chem_cal_rates call
           if (useful) o[RACGPU_O_TGAS] = R.T_good;
-          o[RACGPU_O_EVOLT_END] = (double)R.evolT_end;
+          o[RACGPU_O_EVOLT_END] = (double)R.evolT_end; o[RACGPU_O_TFREEZE_REC] = (double)R.freeze_rec;
           if (N.r_h2form >= 0) o[RACGPU_O_R_H2_FORM] = g_T.rh2;
-        } else { if (useful) o[RACGPU_O_TGAS] = cp[RACGPU_P_TGAS]; o[RACGPU_O_EVOLT_END] = 0.0; }
+        } else { if (useful) o[RACGPU_O_TGAS] = cp[RACGPU_P_TGAS]; o[RACGPU_O_EVOLT_END] = 0.0; o[RACGPU_O_TFREEZE_REC] = 0.0; }
       }
       if (A.stats) {
         long long *s = A.stats + (size_t)cell * RACGPU_NSTAT;
@@ -371,6 +403,15 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
         if (A.i_H2O >= 0) g_col.N_H2O = g_col.N_H2O + w * yc[A.i_H2O];
         if (A.i_OH >= 0) g_col.N_OH = g_col.N_OH + w * yc[A.i_OH];
         if (A.i_CO >= 0) g_col.N_CO = g_col.N_CO + w * yc[A.i_CO];
+        if (A.ray_inner) { // ... and to the rays that leave the star through it
+          const double ws = cp[RACGPU_P_NGAS] * A.ray_ds[cell];
+          double *rn = A.ray_N + (size_t)cell * 4;
+          __hip_atomic_store(rn + 0, g_ray.N_H2 + (N.i_H2 >= 0 ? ws * yc[N.i_H2] : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(rn + 1, g_ray.N_H2O + (A.i_H2O >= 0 ? ws * yc[A.i_H2O] : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(rn + 2, g_ray.N_OH + (A.i_OH >= 0 ? ws * yc[A.i_OH] : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(rn + 3, g_ray.N_CO + (A.i_CO >= 0 ? ws * yc[A.i_CO] : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&A.ray_done[cell], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     dev_mark(c, 6);
@@ -484,6 +525,8 @@ struct racgpu_network {
   long last_team_cells = 0;       // cells the last pass solved four waves at a time
   int *parked_host = nullptr;     // pinned: cells the last pass (its last chunk) handed over to teams at its end
   double *co_logNH2 = nullptr, *co_logNCO = nullptr, *co_lnf = nullptr; int co_nrow = 0, co_ncol = 0; // racgpu_set_co_shielding_table
+  std::vector<int> ray_inner; std::vector<double> ray_ds; // racgpu_set_star_rays (host copies: the sweep checks them against its columns)
+  int last_ray_timeouts = 0;
   bool timed = false;
   int cu_count = 0;
   // heating/cooling (evolT): host tables, their device copy, and the arrays it points at
@@ -1195,7 +1238,8 @@ int racgpu_newton_solve(racgpu_network *h, const racgpu_params *p, const double 
         db(bx, ncell * nS * 8, RACGPU_MEM_HOST, true);
     h->ensure_workspace((long)ncell, (long)ncell);
     const char *rep_env = getenv("RACGPU_DEBUG_REPEAT"); // developer aid: time the factorisation + solve in isolation
-    const int repeat = rep_env ? std::max(1, atoi(rep_env)) : 1;
+    const char *mode_env = getenv("RACGPU_DEBUG_REPEAT_MODE");
+    const int repeat = (rep_env ? std::min(std::max(1, atoi(rep_env)), 0xffffff) : 1) | ((mode_env ? atoi(mode_env) & 3 : 0) << 24);
     long long *cyc_dev = nullptr;
     if (rep_env) { HIP_OK(hipMalloc((void **)&cyc_dev, (size_t)ncell * 8 * sizeof(long long))); HIP_OK(hipMemset(cyc_dev, 0, (size_t)ncell * 8 * sizeof(long long))); }
     hipLaunchKernelGGL(k_newton, dim3((unsigned)ncell), dim3(64), lds_bytes(h->dn), h->stream, h->dn_dev, h->dp_dev, h->ws, (const double *)dc.d,
@@ -1208,9 +1252,9 @@ int racgpu_newton_solve(racgpu_network *h, const racgpu_params *p, const double 
       (void)hipFree(cyc_dev);
       double a[6] = {0, 0, 0, 0, 0, 0};
       for (int64_t c = 0; c < ncell; ++c) for (int k = 0; k < 6; ++k) a[k] += (double)cy[(size_t)c * 8 + k];
-      const double den = (double)ncell * repeat;
+      const double den = (double)ncell * (repeat & 0xffffff);
       fprintf(stderr, "[racgpu debug] %lld cells x %d: cycles per LU %.0f (scatter %.0f, lds pivots %.0f, register pivots %.0f, finish %.0f), per solve %.0f\n",
-              (long long)ncell, repeat, a[0] / den, a[2] / den, a[3] / den, a[4] / den, a[5] / den, a[1] / den);
+              (long long)ncell, repeat & 0xffffff, a[0] / den, a[2] / den, a[3] / den, a[4] / den, a[5] / den, a[1] / den);
     }
     db.copy_out();
   });
@@ -1541,6 +1585,22 @@ int racgpu_set_co_shielding_table(racgpu_network *h, int32_t nrow, int32_t ncol,
   });
 }
 
+int racgpu_set_star_rays(racgpu_network *h, int64_t ncell, const int32_t *inner, const double *ds) {
+  if (!h) return fail("null network");
+  return guarded([&] {
+    h->ray_inner.clear(); h->ray_ds.clear();
+    if (!inner || ncell <= 0) return; // cleared
+    if (!ds) throw std::runtime_error("star rays: ds missing");
+    for (int64_t i = 0; i < ncell; ++i) {
+      if (inner[i] < -1 || inner[i] >= ncell || inner[i] == i) throw std::runtime_error("star rays: inner must name another cell or be -1");
+      if (!(ds[i] >= 0.0)) throw std::runtime_error("star rays: ds must be >= 0");
+    }
+    h->ray_inner.assign(inner, inner + ncell); h->ray_ds.assign(ds, ds + ncell);
+  });
+}
+
+int racgpu_star_ray_timeouts(const racgpu_network *h) { return h ? h->last_ray_timeouts : -1; }
+
 int racgpu_column_sweep(racgpu_network *h, const racgpu_params *p, int64_t ncolumn, const int32_t *col_ptr, const int32_t *col_cells,
                         int64_t ncell, double *cells, double *y, const double *dz, double dv_turb, double *t_final, int32_t *quality,
                         int64_t *stats, double *cell_out, int mem) {
@@ -1568,6 +1628,26 @@ int racgpu_column_sweep(racgpu_network *h, const racgpu_params *p, int64_t ncolu
         seen[col_cells[i]] = 1;
       }
     }
+    // rays to the star: a cell waits (on the device) for the cell its ray passes through next, so that cell must belong to a column
+    // that is taken from the queue EARLIER (columns are started in index order and never wait for later ones: no deadlock)
+    const bool rays = !h->ray_inner.empty();
+    std::unique_ptr<DevBuf> dri, drs;
+    struct DevMem { void *d = nullptr; ~DevMem() { if (d) (void)hipFree(d); } } raymem;
+    double *rayN = nullptr; int *rayflags = nullptr;
+    if (rays) {
+      if ((int64_t)h->ray_inner.size() != ncell) throw std::runtime_error("column sweep: racgpu_set_star_rays was given another number of cells");
+      if (mem != RACGPU_MEM_HOST) throw std::runtime_error("column sweep: star rays need host buffers (the column order is checked on the host)");
+      std::vector<int> colof((size_t)ncell, 0);
+      for (int64_t c = 0; c < ncolumn; ++c) for (int q = col_ptr[c]; q < col_ptr[c + 1]; ++q) colof[col_cells[q]] = (int)c;
+      for (int64_t i = 0; i < ncell; ++i)
+        if (h->ray_inner[i] >= 0 && colof[h->ray_inner[i]] >= colof[i]) throw std::runtime_error("column sweep: a star ray must lead into a column of lower index");
+      dri = std::make_unique<DevBuf>(h->ray_inner.data(), (size_t)ncell * 4, RACGPU_MEM_HOST, true);
+      drs = std::make_unique<DevBuf>(h->ray_ds.data(), (size_t)ncell * 8, RACGPU_MEM_HOST, true);
+      HIP_OK(hipMalloc(&raymem.d, (size_t)ncell * 4 * 8 + (size_t)(ncell + 1) * 4));
+      rayN = (double *)raymem.d;
+      rayflags = (int *)(rayN + (size_t)ncell * 4);
+      HIP_OK(hipMemsetAsync(rayN, 0, (size_t)ncell * 4 * 8 + (size_t)(ncell + 1) * 4, h->stream));
+    }
     h->ws.trace = nullptr; h->ws.marker = nullptr;
     const long grid = std::min<long>(ncolumn, 2L * h->cu_count); // two teams per CU by registers
     h->ensure_workspace(grid, (long)ncell);
@@ -1582,6 +1662,7 @@ int racgpu_column_sweep(racgpu_network *h, const racgpu_params *p, int64_t ncolu
     auto find = [&](const char *nm) { for (int i = 0; i < h->net.nS; ++i) if (h->net.names[i] == nm) return i; return -1; };
     A.i_H2O = find("H2O"); A.i_OH = find("OH"); A.i_CO = find("CO");
     A.co_logNH2 = h->co_logNH2; A.co_logNCO = h->co_logNCO; A.co_lnf = h->co_lnf; A.co_nrow = h->co_nrow; A.co_ncol = h->co_ncol;
+    if (rays) { A.ray_inner = (const int *)dri->d; A.ray_ds = (const double *)drs->d; A.ray_N = rayN; A.ray_done = rayflags; A.ray_timeouts = rayflags + ncell; }
     DevWork Wc = h->ws;
     Wc.counter = h->ws.counter + 6;
     hipLaunchKernelGGL(k_solve_columns, dim3((unsigned)grid), dim3(64 * kTeam), lds_bytes_team(h->dn), h->stream, h->dn_dev, h->dp_dev, Wc, A);
@@ -1591,6 +1672,11 @@ int racgpu_column_sweep(racgpu_network *h, const racgpu_params *p, int64_t ncolu
     if (mem == RACGPU_MEM_HOST) {
       HIP_OK(hipStreamSynchronize(h->stream));
       dc.copy_out(); dy.copy_out(); dt.copy_out(); dq.copy_out(); ds.copy_out(); dout.copy_out();
+      h->last_ray_timeouts = 0;
+      if (rays) {
+        HIP_OK(hipMemcpy(&h->last_ray_timeouts, rayflags + ncell, sizeof(int), hipMemcpyDeviceToHost));
+        if (h->last_ray_timeouts) throw std::runtime_error("column sweep: " + std::to_string(h->last_ray_timeouts) + " cell(s) gave up waiting for the cell on their ray to the star");
+      }
     }
   });
 }

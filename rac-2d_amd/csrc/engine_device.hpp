@@ -443,6 +443,12 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   const rsrc_t bLrow = mkbuf(N.Lrow), bUrow = mkbuf(N.Urow), bProw = mkbuf(N.Prow), bUdesc = mkbuf(N.Udesc), bP = mkbuf(Pv), bL = mkbuf(Lv),
                bU = mkbuf(Uv);
   const int l2 = lane * 2, l8 = lane * 8; // lane part of every byte offset (u16 and 8-byte arrays)
+#ifdef RG_EXP_LSHARED // timing experiment (k_newton only, results are garbage): every wave reads the L pieces of its LDS pivots from cell 0's slice
+  const rsrc_t bLexp = mkbuf(Lv - (size_t)blockIdx.x * N.nzl);
+#define RG_EXP_BL bLexp
+#else
+#define RG_EXP_BL bL
+#endif
   const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column (team mode: first the wave's own list)
   auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; r.j = c[9]; return r; };
   for (int i = lane; i < n; i += 64) w[i] = 0.0; // the work column is kept all-zero between columns
@@ -507,7 +513,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     const int hi_ = __builtin_amdgcn_readlane(dhi, (tt));                                                          \
     ds[S] = __builtin_amdgcn_readlane(dlo, (tt));                                                                  \
     const int a2_ = hi_ & 0x1fffff, o8_ = min(l8, (int)((unsigned)hi_ >> 21));                                     \
-    i[S] = bload_u16(bLrow, o8_ >> 2, a2_); l[S] = sload_f64(bL, o8_, a2_ << 2);                                   \
+    i[S] = bload_u16(bLrow, o8_ >> 2, a2_); l[S] = sload_f64(RG_EXP_BL, o8_, a2_ << 2);                            \
   }
 #pragma unroll
       for (int s = 0; s < D - 1; ++s) { RG_LU_ISSUE(s, s) __builtin_amdgcn_sched_barrier(0); } // keep the issue order: data returns in order

@@ -60,7 +60,7 @@ static __shared__ volatile WaveConst g_wc;
 struct TSlot {
   double y, savf, acor, ewt, rtol, atol, yh[6];
   double Pc[10], Pd, schur, rh2, t_scale_tol;
-  int evolT, maySwitchT;
+  int evolT, maySwitchT, freeze_rec;
 };
 static __shared__ volatile TSlot g_T;
 // wave 0's requests to the other waves of its team (k_solve_team): written before a barrier, read after it
@@ -859,7 +859,7 @@ RG_DEV void dev_lsodes_call(const DevNet &N, const DevParams &P, const CellCtx &
 // ygood (HBM): the hand-off record, i.e. record(:, isav) of the caller's loop in calc_this_cell (reference
 // src/disk.f90:1716-1733): the last record whose T and H2 entries are not NaN.
 struct CellResult { double t_final, t_good; int quality, nerr, nrec_real, isav; long long nst, nfe, nje, nlu, qsum, errc; int nfail; bool parked;
-                    double T_good; int evolT_end; }; // ET: T of the hand-off record; whether T was still evolving at the end
+                    double T_good; int evolT_end, freeze_rec; }; // ET: T of the hand-off record; whether T was still evolving at the end
 // ET: the last records' T and times for the T-freeze test of chem_evol_solve (reference src/chemistry.f90:532-546), T of the hand-off record
 struct THist { double T[8], t[8], T_good; };
 static __shared__ volatile THist g_Th;
@@ -967,7 +967,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
         double T1 = g_Th.T[i & 7], T2 = T1;
         for (int k = 1; k < 5; ++k) { const double v = g_Th.T[(i - k) & 7]; T1 = fmax(T1, v); T2 = fmin(T2, v); }
         const double dtt = g_Th.t[i & 7] - g_Th.t[(i - 5) & 7];
-        if ((T1 - T2) < g_T.t_scale_tol * (T1 + T2) * dtt / s.tcrit) { istate = 1; g_T.evolT = 0; }
+        if ((T1 - T2) < g_T.t_scale_tol * (T1 + T2) * dtt / s.tcrit) { istate = 1; g_T.evolT = 0; g_T.freeze_rec = i; }
       }
     }
     if (P.steps_reset > 0 && i % P.steps_reset == 0) istate = 1;
@@ -1014,7 +1014,7 @@ RG_DEV CellResult dev_evol_solve(const DevNet &N, const DevParams &P, const Cell
   CellResult R{};
   R.t_final = t; R.t_good = e.t_good; R.isav = e.isav; R.quality = qual; R.nerr = e.nerr; R.nrec_real = nrr;
   R.nst = e.nst_acc; R.nfe = e.nfe_acc; R.nje = e.nje_acc; R.nlu = e.nlu_acc; R.qsum = s.qsum; R.nfail = s.nfail; R.errc = e.errc;
-  if constexpr (ET) { R.T_good = g_Th.T_good; R.evolT_end = g_T.evolT; }
+  if constexpr (ET) { R.T_good = g_Th.T_good; R.evolT_end = g_T.evolT; R.freeze_rec = g_T.freeze_rec; }
   return R;
 }
 

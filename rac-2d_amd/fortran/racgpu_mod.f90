@@ -23,7 +23,7 @@ module racgpu
             heating_cooling_to_c, racgpu_hc_config_default, racgpu_heating_cooling_load, racgpu_evolT_solve_batch
   public :: racgpu_multi_create, racgpu_multi_destroy, racgpu_multi_calc_cells, racgpu_multi_error_string
 
-  integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 20, RACGPU_NOUT = 5, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
+  integer, parameter :: RACGPU_NPAR = 28, RACGPU_NSTAT = 20, RACGPU_NOUT = 6, RACGPU_MEM_HOST = 0, RACGPU_MEM_DEVICE = 1
   integer, parameter :: RACGPU_F_RECTIFY = 1
   integer, parameter :: RACGPU_NHC = 28 ! per-cell heating/cooling record (include/racgpu.h, RACGPU_H_*)
 

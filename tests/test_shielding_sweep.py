@@ -194,3 +194,122 @@ def test_column_sweep_on_the_device_is_the_layer_sweep(racgpu):
     # floor of DESIGN.md section 2 (1e-5 ... 1e-3); most cells do not notice
     assert np.median(rel) < 1e-9 and np.quantile(rel, 0.9) < 1e-5 and rel.max() < 3e-3, (rel.max(), np.quantile(rel, 0.9), np.median(rel))
     assert (dev["quality"] == 0).all() and (dev["t_final"] == 1e3).all()
+
+
+def test_wavefronts_of_a_column_grid_with_star_rays(racgpu):
+    """Host logic of the dependency-order sweep with rays to the star: in the configs[2] grid's structure (rays along a layer) a cell
+    waits for the one above it and the one inwards of it, so the levels are the anti-diagonals column + layer; without rays, the layers.
+    The numpy update accumulates the same column densities as column_density_above."""
+    C = racgpu.cells
+    g = C.andrews_columns(7, 5)
+    lev = C.wavefronts(g["col_ptr"], g["col_cells"], g["inner"])
+    np.testing.assert_array_equal(lev, g["column"] + g["layer"])
+    np.testing.assert_array_equal(C.wavefronts(g["col_ptr"], g["col_cells"]), g["layer"])
+    ncell = 35
+    rng = np.random.default_rng(3)
+    cells = np.zeros((ncell, racgpu.NPAR)); cells[:, C.P_NGAS] = 10.0 ** rng.uniform(4, 10, ncell)
+    y = 10.0 ** rng.uniform(-8, -1, (ncell, 4))
+    upd = C.shielding_update(None, 1.3e5, dict(H2=0, H2O=1, OH=2, CO=3), g["col_ptr"], g["col_cells"], g["dz"], g["inner"], g["ds"])
+    done = np.zeros(0, dtype=np.int64)
+    for k in np.unique(lev):
+        idx = np.nonzero(lev == k)[0]
+        upd(int(k), idx, cells, y, done)
+        done = np.concatenate([done, idx])
+    n = cells[:, C.P_NGAS] * y[:, 0]
+    N_ism = C.column_density_above(n, g["dz"], g["column"], g["layer"])
+    np.testing.assert_allclose(cells[:, C.P_FSS_ISM_H2], C.h2_self_shielding(N_ism, 1.3e5), rtol=1e-9)  # (column_density_above differences two running sums)
+    # towards the star: the same sum along a layer, over the columns further in
+    N_star = C.column_density_above(n, g["ds"], g["layer"], g["column"])
+    np.testing.assert_allclose(cells[:, C.P_FSS_STAR_H2], C.h2_self_shielding(N_star, 1.3e5), rtol=1e-9)  # (column_density_above differences two running sums)
+    N_oh = C.column_density_above(cells[:, C.P_NGAS] * y[:, 2], g["ds"], g["layer"], g["column"])
+    np.testing.assert_allclose(cells[:, C.P_FSS_STAR_OH], C.lya_self_shielding(N_oh, C.LYA_CROSS_OH), rtol=1e-9)  # (column_density_above differences two running sums)
+
+
+@pytest.mark.gpu
+def test_column_sweep_with_star_rays_is_the_wavefront_sweep(racgpu):
+    """racgpu_column_sweep with racgpu_set_star_rays: the toStar slots as well, a cell waiting on the device for the cell its ray to
+    the star enters next.  Against the host-driven sweep over the dependency levels (anti-diagonals of the grid) with the same update in
+    numpy: slots to rounding (two libms) and the noise of their inputs, end states to the integrator's noise floor."""
+    net = racgpu.Network(os.path.join(ROOT, "data", "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat"))
+    y0 = net.load_initial_abundances(os.path.join(ROOT, "data", "ini_abund_waterice_loMetal.dat"))
+    C = racgpu.cells
+    ncol, nz = 8, 6
+    grid = C.andrews_grid(ncol=ncol, nz=nz, rmin=30.0, rmax=120.0)   # (thin enough that the shielding factors are not all saturated)
+    g = C.andrews_columns(ncol, nz, rmin=30.0, rmax=120.0)
+    p = racgpu.default_params(); p.t_max = 1e3
+    grid[:, C.P_TMAX] = 0.0
+    sp = {nm: net.species_index(nm) - 1 for nm in ("H2", "H2O", "OH", "CO")}
+    dv = 1.3e5
+    table = (G["co_logN_H2"], G["co_logN_12CO"], G["co_f_nodes"])
+    lev = C.wavefronts(g["col_ptr"], g["col_cells"], g["inner"])
+    cells_h = grid.copy()
+    upd = C.shielding_update(table, dv, sp, g["col_ptr"], g["col_cells"], g["dz"], g["inner"], g["ds"])
+    host = racgpu.sweep.solve_by_layers(lambda cb, yb: net.evol_solve_batch(p, cb, yb), cells_h, net.init_abundances(y0, grid), lev, upd)
+    net.set_co_shielding_table(table)
+    net.set_star_rays(g["inner"], g["ds"])
+    dev = net.column_sweep(p, grid, net.init_abundances(y0, grid), g["col_ptr"], g["col_cells"], g["dz"], dv_turb=dv)
+    net.set_star_rays(None)
+    plain = net.column_sweep(p, grid, net.init_abundances(y0, grid), g["col_ptr"], g["col_cells"], g["dz"], dv_turb=dv)
+    net.set_co_shielding_table(None)
+    star = [C.P_FSS_STAR_H2, C.P_FSS_STAR_H2O, C.P_FSS_STAR_OH, C.P_FSS_STAR_CO]
+    ism = [C.P_FSS_ISM_H2, C.P_FSS_ISM_H2O, C.P_FSS_ISM_OH, C.P_FSS_ISM_CO]
+    np.testing.assert_array_equal(plain["cells"][:, star], grid[:, star])       # without rays the toStar slots stay as given
+    for slot in star + ism:
+        np.testing.assert_allclose(dev["cells"][:, slot], cells_h[:, slot], rtol=1e-4 if slot in (C.P_FSS_ISM_CO, C.P_FSS_STAR_CO) else 1e-6)
+    assert (dev["cells"][:, star] != grid[:, star]).any(axis=0).all()          # (every toStar slot was rewritten somewhere)
+    first = g["column"] == 0                                                    # the innermost column sees no gas towards the star
+    np.testing.assert_allclose(dev["cells"][first][:, C.P_FSS_STAR_H2], 0.965 + float(np.float32(0.035)) * np.exp(-8.5e-4), rtol=1e-15)
+    assert (dev["cells"][first][:, [C.P_FSS_STAR_H2O, C.P_FSS_STAR_OH]] == 1.0).all()
+    untouched = [k for k in range(racgpu.NPAR) if k not in star + ism]
+    np.testing.assert_array_equal(dev["cells"][:, untouched], grid[:, untouched])
+    big = host["y"] >= 1e-6
+    rel = np.abs(dev["y"] / np.where(big, host["y"], 1.0) - 1.0)[big]
+    assert np.median(rel) < 1e-9 and np.quantile(rel, 0.9) < 1e-5 and rel.max() < 3e-3, (rel.max(), np.quantile(rel, 0.9), np.median(rel))
+    assert (dev["quality"] == 0).all() and (dev["t_final"] == 1e3).all()
+    # a ray into a column that is not started earlier is refused
+    bad = g["inner"].copy(); bad[0] = nz
+    net.set_star_rays(bad, g["ds"])
+    with pytest.raises(racgpu.RacgpuError):
+        net.column_sweep(p, grid, net.init_abundances(y0, grid), g["col_ptr"], g["col_cells"], g["dz"], dv_turb=dv)
+    net.set_star_rays(None)
+
+
+def test_shipped_visser_table_reproduces_the_references_co_shielding():
+    """data/visser2009_co_shielding.dat (the reference's own table, extracted as data) through cells.co_shielding against the
+    compiled reference's get_12CO_shielding at 256 random column-density pairs BETWEEN the nodes (tests/golden/shielding.npz, made from
+    oracle/_ref/ref_shielding): the interpolation of src/load_Visser_CO_selfshielding.f90:271-309 to rounding."""
+    table = R.cells.load_co_shielding_table(os.path.join(ROOT, "data", "visser2009_co_shielding.dat"))
+    assert table[0].shape == (42,) and table[1].shape == (47,) and table[2].shape == (47, 42)
+    got = R.cells.co_shielding(table, G["co_N_H2"], G["co_N_12CO"])
+    want = np.clip(G["co_f"], 0.0, 1.0)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_device_co_interpolation_on_the_shipped_visser_table(racgpu):
+    """The device's get_12CO_shielding (engine.hip, k_solve_columns) on the reference's own table: 64 two-cell columns whose upper
+    cells put a spread of H2 and CO column densities above the lower ones; the CO slots the device writes against cells.co_shielding
+    (pinned to the compiled reference above) on the column densities the upper cells actually ended with."""
+    net = racgpu.Network(os.path.join(ROOT, "data", "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat"))
+    y0 = net.load_initial_abundances(os.path.join(ROOT, "data", "ini_abund_waterice_loMetal.dat"))
+    C = racgpu.cells
+    table = C.load_co_shielding_table(os.path.join(ROOT, "data", "visser2009_co_shielding.dat"))
+    ncol = 64
+    base = C.andrews_grid(ncol=8, nz=6)[20]
+    grid = np.tile(base, (2 * ncol, 1)); grid[:, C.P_TMAX] = 0.0
+    rng = np.random.default_rng(11)
+    dz = np.repeat(10.0 ** rng.uniform(6.0, 17.0, ncol), 2)      # N_H2 from ~1e13 to ~1e24 cm^-2 for n_gas ~ 1e7
+    p = racgpu.default_params(); p.t_max = 1.0
+    col_ptr = np.arange(ncol + 1) * 2; col_cells = np.arange(2 * ncol)
+    y = net.init_abundances(y0, grid)
+    iH2, iCO = net.species_index("H2") - 1, net.species_index("CO") - 1
+    y[::2, iCO] = 10.0 ** rng.uniform(-9.0, -4.0, ncol)           # (the upper cells start with a spread of CO)
+    net.set_co_shielding_table(table)
+    out = net.column_sweep(p, grid, y, col_ptr, col_cells, dz, dv_turb=1e5)
+    net.set_co_shielding_table(None)
+    up = np.arange(0, 2 * ncol, 2); lo = up + 1
+    N_H2 = (grid[up, C.P_NGAS] * dz[up]) * out["y"][up, iH2]; N_CO = (grid[up, C.P_NGAS] * dz[up]) * out["y"][up, iCO]
+    want = C.co_shielding(table, N_H2, N_CO)
+    assert want.min() < 1e-3 and want.max() > 0.9                  # (the spread covers the table)
+    np.testing.assert_allclose(out["cells"][lo, C.P_FSS_ISM_CO], want, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(out["cells"][up, C.P_FSS_ISM_CO], C.co_shielding(table, 0.0, 0.0), rtol=1e-12)

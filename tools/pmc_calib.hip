@@ -15,6 +15,20 @@ __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, double v) {
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
 }
+template <int AUX>
+__device__ __forceinline__ double bload_aux(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX)); }
+// the same sweeps with the `nt` cache policy (aux = 2), which the triangular solves use on the factor streams
+__global__ __launch_bounds__(64) void k_calib_read_nt(const double *src, long nper, int reps, double *out) {
+  const rsrc_t b = mkbuf(src + (size_t)blockIdx.x * nper);
+  double s = 0.0;
+  for (int r = 0; r < reps; ++r)
+    for (long i0 = 0; i0 < nper; i0 += 64 * 4) {
+      const double a0 = bload_aux<2>(b, threadIdx.x * 8, (int)(i0 * 8)), a1 = bload_aux<2>(b, threadIdx.x * 8, (int)(i0 * 8 + 512)),
+                   a2 = bload_aux<2>(b, threadIdx.x * 8, (int)(i0 * 8 + 1024)), a3 = bload_aux<2>(b, threadIdx.x * 8, (int)(i0 * 8 + 1536));
+      s += (a0 + a1) + (a2 + a3);
+    }
+  if (s == 12345.678) out[blockIdx.x] = s;
+}
 // one wave per workgroup, slice of nper doubles per wave, `reps` sweeps over it
 __global__ __launch_bounds__(64) void k_calib_read(const double *src, long nper, int reps, double *out) {
   const rsrc_t b = mkbuf(src + (size_t)blockIdx.x * nper);
@@ -47,6 +61,11 @@ int main() {
   OK(hipDeviceSynchronize());
   hipLaunchKernelGGL(k_calib_read, dim3(waves), dim3(64), 0, 0, buf, nper_slice, 8, out);
   OK(hipDeviceSynchronize());
+  hipLaunchKernelGGL(k_calib_read_nt, dim3(waves), dim3(64), 0, 0, buf, nper_stream, 1, out);
+  OK(hipDeviceSynchronize());
+  hipLaunchKernelGGL(k_calib_read_nt, dim3(waves), dim3(64), 0, 0, buf, nper_slice, 8, out);
+  OK(hipDeviceSynchronize());
+  printf("{\"k_calib_read_nt_stream_bytes\": %ld, \"k_calib_read_nt_reread_bytes\": %ld}\n", waves * nper_stream * 8, waves * nper_slice * 8 * 8);
   printf("{\"k_calib_write_bytes\": %ld, \"k_calib_read_stream_bytes\": %ld, \"k_calib_read_reread_bytes\": %ld, \"reread_footprint_bytes\": %ld}\n",
          waves * nper_stream * 8, waves * nper_stream * 8, waves * nper_slice * 8 * 8, waves * nper_slice * 8);
   return 0;
