@@ -260,7 +260,8 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                   "nerr_total_reference": int(codes_ref.sum()), "nerr_total_reference_twin": int(codes_twin.sum()), "nerr_total_gpu": int(codes_gpu.sum())}
         if frz:  # evolT: the T-freeze test (src/chemistry.f90:532-546) is a threshold inside the integrator's noise; see RACGPU_O_TFREEZE_REC
             same = np.array([a == b for a, b in frz])
-            parity["T_freeze"] = {"cells_frozen_at_the_same_record": int(same.sum()), "cells_frozen_at_different_records": int((~same).sum()),
+            twin_same = int(sum(ref_freeze_rec(ref[k]) == ref_freeze_rec(twin[k]) for k in range(nsample))) if twin is not None else None
+            parity["T_freeze"] = {"cells_frozen_at_the_same_record": int(same.sum()), "reference_vs_its_twin_same_record": twin_same, "cells_frozen_at_different_records": int((~same).sum()),
                                   "max_rel_err_where_same": float(errs[same].max()) if same.any() else None,
                                   "cells_within_bound_where_same": int((errs[same] <= bound[same]).sum()),
                                   "max_rel_err_where_different": float(errs[~same].max()) if (~same).any() else None}

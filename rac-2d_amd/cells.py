@@ -257,10 +257,7 @@ def co_shielding(table, N_H2, N_12CO):
     return np.minimum(1.0, np.maximum(0.0, np.exp(v)))
 
 
-def load_co_shielding_table(path):
-    """The reference's own 12CO shielding table (Visser, van Dishoeck & Black 2009) as shipped in data/visser2009_co_shielding.dat
-    (written by tools/extract_reference_tables.py from the DATA statements of src/load_Visser_CO_selfshielding.f90): returns the
-    (logN_H2 [nrow], logN_12CO [ncol], f [ncol, nrow]) triple co_shielding and Network.set_co_shielding_table take."""
+def _load_tables(path):
     arrs = {}
     name, shape, vals = None, None, []
     for line in open(path):
@@ -275,7 +272,56 @@ def load_co_shielding_table(path):
             vals.extend(float(v) for v in line.split())
     if name:
         arrs[name] = (shape, vals)
-    out = {k: np.array(v, dtype=np.float64).reshape(sh, order="F") for k, (sh, v) in arrs.items()}  # (column-major, as Fortran holds them)
+    return {k: np.array(v, dtype=np.float64).reshape(sh, order="F") for k, (sh, v) in arrs.items()}  # (column-major, as Fortran holds them)
+
+
+def load_xray_cross_sections(path):
+    """data/bethell2011_xray_cross.dat (Bethell & Bergin 2011, Table 2, as the reference tabulates it in src/load_Bethell_Xray.f90):
+    dict(E_r [2, 16] keV, c_g [3, 16], c_d [3, 16]) for sigma_xray_bethell."""
+    return _load_tables(path)
+
+
+def sigma_xray_bethell(table, E_keV, dust_depletion, d2h, grain_radius_cm):
+    """sigma_Xray_Bethell (reference src/load_Bethell_Xray.f90:70-96): X-ray photoabsorption cross section per H nucleus [cm^2] at photon
+    energy E [keV] -- gas plus dust, the dust part reduced by grain self-shielding f(tau), tau = sigma_dust / G * 3 / (2 pi) / a^2.
+    The band is the first whose range holds E (the bands share their end points), the first / last one outside the table."""
+    E = np.atleast_1d(np.asarray(E_keV, dtype=np.float64))
+    Er, cg, cd = table["E_r"], table["c_g"], table["c_d"]
+    inside = (E[:, None] >= Er[0][None, :]) & (E[:, None] <= Er[1][None, :])
+    i0 = np.where(inside.any(1), inside.argmax(1), np.where(E < Er[0, 0], 0, Er.shape[1] - 1))
+    sd = 1e-24 / (E * E * E) * (cd[0, i0] + (cd[1, i0] + cd[2, i0] * E) * E) * dust_depletion
+    sg = 1e-24 / (E * E * E) * (cg[0, i0] + (cg[1, i0] + cg[2, i0] * E) * E)
+    if dust_depletion <= 1e-30 or d2h <= 1e-30:
+        f = np.ones_like(E)
+    else:
+        tau = sd / d2h * (3.0 / (2.0 * math.pi)) / (grain_radius_cm * grain_radius_cm)
+        f = 1.5 / tau * (1.0 - 2.0 / tau / tau * (1.0 - (tau + 1.0) * np.exp(-tau)))
+    out = sg + f * sd
+    return out if np.ndim(E_keV) else float(out[0])
+
+
+def xray_ionization_rate(table, lam_angstrom, local_flux, dust_depletion, d2h, grain_radius_cm, en_per_ion_eV=37.0):
+    """calc_Xray_ionization_rate (reference src/disk.f90:1969-2010) for one cell: zeta_Xray_H2 [s^-1 per H] = sum over the wavelength bins
+    of the X-ray range of local_flux_i / E_i * sigma(E_i) * (E_i / 37 eV), E_i = h c / lambda_i.  lam_angstrom [n] are the bins the
+    caller's loop runs over (i1..i2 of dust_0%lam, its own range selection), local_flux [n] the photon ENERGY flux in each bin
+    [erg s^-1 cm^-2] -- the cell's radiation field (c%optical%flux), or with calc_zetaXray_from_Ncol the star's spectrum attenuated by
+    exp(-sigma N_toStar) / (4 pi r^2).  Both are inputs from the radiative transfer: zeta_Xray does not depend on the chemistry, so it is a
+    per-cell preprocessing of the record (RACGPU_P_ZETA_X), not part of the sweep."""
+    h, c, eV = 6.62606896e-27, 2.99792458e10, 1.60217657e-12   # phy_hPlanck_CGS, phy_SpeedOfLight_CGS, phy_eV2erg (src/sub_global_variables.f90)
+    lam = np.asarray(lam_angstrom, dtype=np.float64)
+    en = h * c / (lam * 1e-8) / eV / 1e3                        # keV
+    sig = sigma_xray_bethell(table, en, dust_depletion, d2h, grain_radius_cm)
+    z = 0.0
+    for e, s, fl in zip(en, sig, np.asarray(local_flux, dtype=np.float64)):   # (the reference's running sum, in bin order)
+        z = z + fl / (e * 1e3 * eV) * s * (e * 1e3 / en_per_ion_eV)
+    return z
+
+
+def load_co_shielding_table(path):
+    """The reference's own 12CO shielding table (Visser, van Dishoeck & Black 2009) as shipped in data/visser2009_co_shielding.dat
+    (written by tools/extract_reference_tables.py from the DATA statements of src/load_Visser_CO_selfshielding.f90): returns the
+    (logN_H2 [nrow], logN_12CO [ncol], f [ncol, nrow]) triple co_shielding and Network.set_co_shielding_table take."""
+    out = _load_tables(path)
     return out["logN_H2"], out["logN_12CO"], out["f_12CO"]
 
 

@@ -87,6 +87,7 @@ struct DevNet {
   int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;
   int i_H2;                  // hand-off test (reference src/disk.f90:1716-1721)
   int grain_conserved;       // 1: every reaction has as many Grain0/Grain-/Grain+ among its reactants as among its products (dev_rhs)
+  int moeq_r61, moeq_r62;    // H2_form_use_moeq: the adsorption reaction of H and the desorption reaction of gH (-1 none)
   int r_h2form;              // last reaction whose coefficient the reference copies into R_H2_form_rate_coeff (-1 none)
   const uint8_t *s_tolclass; // 0 generic, 1 one of the ten special species, 2 Grain0/+/-, 3 surface species (applied in that order)
   const int8_t *s_charge;    // elements(1, :) of every species (rectify_abundances, reference src/chemistry.f90:2170-2201)
@@ -94,7 +95,7 @@ struct DevNet {
 
 struct DevParams {
   double RTOL, ATOL, t_max, dt_first_step, ratio_tstep, Diff2DesorRatio, special_gH_E_diff;
-  int mxstep, steps_reset, use_special_gH_mobi, tol_j;
+  int mxstep, steps_reset, use_special_gH_mobi, tol_j, h2_moeq;
   long long max_steps_per_cell;
   double max_runtime_allowed; // seconds of MODELLED reference CPU time (<= 0: guards off)
   double rt_cost_f, rt_cost_jac, rt_cost_lu; // modelled seconds per f evaluation / Jacobian / factorisation (racgpu_params)

@@ -873,6 +873,22 @@ void racgpu_network::upload() {
   dn.r_h2form = -1; // chem_cal_rates stores the coefficient of every itype-0 and every gH-first itype-63 reaction in turn: the last one stays
   for (int r = 0; r < nR; ++r)
     if (h.R[r].itype == 0 || (h.R[r].itype == 63 && h.R[r].rname[0] == "gH")) dn.r_h2form = r;
+  // H2_form_use_moeq (src/chemistry.f90:876-881) reads adsorb_coeff(counterpart of gH) and desorb_coeff(gH): the last adsorption
+  // reaction of that species and the last desorption reaction of gH BEFORE the first gH-first itype-63 reaction in the file (a later one
+  // would hand the coefficient of the previous chem_cal_rates call to it: such a network is refused when the switch is on, -2)
+  dn.moeq_r61 = dn.moeq_r62 = -1;
+  {
+    int first63 = -1;
+    for (int r = 0; r < nR && first63 < 0; ++r) if (h.R[r].itype == 63 && h.R[r].rname[0] == "gH") first63 = r;
+    if (first63 >= 0) {
+      const int gH = h.R[first63].reac[0], H = h.counterpart[gH - 1];
+      for (int r = 0; r < nR; ++r) {
+        if (h.R[r].itype == 61 && h.R[r].reac[0] == H) dn.moeq_r61 = r < first63 ? r : -2;
+        if (h.R[r].itype == 62 && h.R[r].reac[0] == gH) dn.moeq_r62 = r < first63 ? r : -2;
+      }
+      if (dn.moeq_r61 < 0 || dn.moeq_r62 < 0) dn.moeq_r61 = dn.moeq_r62 = -2; // (the switch cannot be honoured on this network)
+    }
+  }
   HIP_OK(hipEventCreate(&ev0));
   HIP_OK(hipEventCreate(&ev1));
   HIP_OK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -955,14 +971,14 @@ static void cfode_bdf(DevParams &P) { // BDF method coefficients, orders 1..5 (D
   }
 }
 
+static void check_moeq(const racgpu_network *h, const DevParams &P);
 static DevParams to_dev(const racgpu_params *p) {
-  if (p->H2_form_use_moeq) throw std::runtime_error("H2_form_use_moeq = .true. is not implemented (see DESIGN.md, out of scope rows)");
   if (p->evol_dust_size) throw std::runtime_error("evol_dust_size = .true. is not implemented");
   if (!(p->dt_first_step > 0.0) || !(p->ratio_tstep > 1.0) || !(p->t_max > 0.0)) throw std::runtime_error("need dt_first_step > 0, ratio_tstep > 1, t_max > 0");
   DevParams P{};
   P.RTOL = p->RTOL; P.ATOL = p->ATOL; P.t_max = p->t_max; P.dt_first_step = p->dt_first_step; P.ratio_tstep = p->ratio_tstep;
   P.Diff2DesorRatio = p->Diff2DesorRatio; P.special_gH_E_diff = p->special_gH_E_diff;
-  P.mxstep = p->mxstep_per_interval; P.steps_reset = p->steps_reset_solver; P.use_special_gH_mobi = p->use_special_gH_mobi;
+  P.mxstep = p->mxstep_per_interval; P.steps_reset = p->steps_reset_solver; P.use_special_gH_mobi = p->use_special_gH_mobi; P.h2_moeq = p->H2_form_use_moeq ? 1 : 0;
   P.tol_j = p->tol_policy_j > 0 ? p->tol_policy_j : 1;
   P.max_steps_per_cell = p->max_steps_per_cell;
   P.max_runtime_allowed = p->max_runtime_allowed;
@@ -1178,7 +1194,7 @@ int racgpu_rates(racgpu_network *h, const racgpu_params *p, const double *cells,
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dr(rates, (size_t)ncell * h->dn.nR * 8, RACGPU_MEM_HOST, false);
     hipLaunchKernelGGL(k_rates, dim3((unsigned)ncell), dim3(64), 0, h->stream, h->dn_dev, h->dp_dev, (const double *)dc.d, (double *)dr.d, (double *)nullptr);
@@ -1193,7 +1209,7 @@ int racgpu_rhs(racgpu_network *h, const racgpu_params *p, const double *cells, i
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
@@ -1212,7 +1228,7 @@ int racgpu_jac_csc(racgpu_network *h, const racgpu_params *p, const double *cell
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
@@ -1231,7 +1247,7 @@ int racgpu_newton_solve(racgpu_network *h, const racgpu_params *p, const double 
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
@@ -1414,8 +1430,13 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
 
 static void ensure_hc(racgpu_network *h) { if (!h->hc_dev) h->upload_hc(); }
 
+static void check_moeq(const racgpu_network *h, const DevParams &P) {
+  if (P.h2_moeq && h->dn.moeq_r61 == -2)
+    throw std::runtime_error("H2_form_use_moeq: the network's adsorption reaction of H and desorption reaction of gH must precede its gH + gH reaction");
+}
+
 static void push_params(racgpu_network *h, const DevParams &P) {
-  HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+  check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream)); // P lives on the caller's stack frame
 }
 

@@ -189,6 +189,22 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
       case 63: {
         const double tmp = dev_mobility(P, gptr(N.s_vib)[a], gptr(N.s_mass)[a], gptr(N.s_Edes)[a], Tdust) / sites;
         k = tmp / D2H * dev_branching(it, A, B, C, T0, Tdust);
+        if ((gptr(N.r_flags)[r] & 2) && P.h2_moeq && N.moeq_r61 >= 0 && N.moeq_r62 >= 0) {
+          // chemsol_params%H2_form_use_moeq (src/chemistry.f90:876-881): gH + gH by the rate equation's steady state,
+          // k_mig / (k_mig + desorb_coeff(gH)) * adsorb_coeff(H) / D2H, the two coefficients as the adsorption (:806-826) and desorption
+          // (:827-846, before the surface-layer factor) cases of this same call leave them
+          const int r61 = N.moeq_r61, r62 = N.moeq_r62, h = gptr(N.r_re0)[r61];
+          double ads = 0.0;
+          if (Tgas > 0.0) {
+            const double m = gptr(N.s_mass)[h] * cst::mP;
+            ads = dev_sticking(gptr(N.s_mass)[h], Tgas) * gptr(N.r_A)[r61] * sig * cell[5] * sqrt(8.0 / cst::Pi * cst::kB * Tgas / m);
+            if (sig <= 1e-30) ads = 0.0;
+          }
+          const double C62 = gptr(N.r_C)[r62];
+          double des = gptr(N.s_vib)[a] * (exp(-C62 / Tdust) + cst::CosmicDesorpPre * cr * exp(-C62 / cst::CosmicDesorpT));
+          if (sig <= 1e-30) des = 0.0;
+          k = tmp / (tmp + des) * ads / D2H;
+        }
         if ((gptr(N.r_flags)[r] & 2) && sig <= 1e-30) k = 0.0;
       } break;
       case 64:

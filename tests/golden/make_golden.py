@@ -60,7 +60,7 @@ def read_cell(fn):
 
 
 def run_ref(network, initial, cells, rtol, t_max, steps_reset, dump_jac, solve=1, atol=1e-30, mxstep=6000, nlocal_iter=1, tol_j=1,
-            y_override=None, special_gH_mobi=False, dump_analysis=0, hc=None, may_switch_T=1):
+            y_override=None, special_gH_mobi=False, dump_analysis=0, hc=None, may_switch_T=1, h2_moeq=False):
     """y_override: list of (cell (1-based), species (1-based), value) applied to the initial condition.
     hc: heating/cooling records [ncell, 28] -> the run is made with the gas temperature co-evolving (evolT)."""
     with tempfile.TemporaryDirectory() as td:
@@ -70,6 +70,8 @@ def run_ref(network, initial, cells, rtol, t_max, steps_reset, dump_jac, solve=1
             np.savetxt(os.path.join(td, "hc.txt"), hc, fmt="%.17e")
             ov += " evolT=1\n may_switch_T=%d\n hc_file='%s'\n enthalpy='Species_enthalpy.dat'\n transitions_dir='/root/reference/transitions/'\n" % (
                 may_switch_T, os.path.join(td, "hc.txt"))
+        if h2_moeq:
+            ov += " h2_moeq=.true.\n"
         if y_override:
             with open(os.path.join(td, "override.txt"), "w") as f:
                 for c, sp, v in y_override:
@@ -393,6 +395,20 @@ def main_evolT():
     print("wrote", fn, os.path.getsize(fn) // 1024, "KiB")
 
 
+def main_moeq():
+    """tests/golden/moeq_grain.npz: chemsol_params%H2_form_use_moeq = .true. (src/chemistry.f90:876-881) on the grain network: the rate
+    coefficients of four cells and the end state of two (RTOL 1e-8)."""
+    network, initial = "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "ini_abund_waterice_loMetal.dat"
+    cells = np.array([make_cell(*c) for c in CELLS[:4]])
+    r, _ = run_ref(network, initial, cells, 1e-8, 1e4, 50, 0, h2_moeq=True)
+    r0, _ = run_ref(network, initial, cells[:1], 1e-8, 1e4, 50, 0, solve=0)
+    np.savez_compressed(os.path.join(HERE, "moeq_grain.npz"), network_file=network, initial_file=initial, cells=cells, t_max=1e4, rtol=1e-8,
+                        rates=np.array([x["rates"] for x in r]), yend=np.array([x["yend"] for x in r]), scalars=np.array([x["scalars"] for x in r]),
+                        rates_default_cell0=r0[0]["rates"])
+    d = np.nonzero(r[0]["rates"] != r0[0]["rates"])[0]
+    print("wrote moeq_grain.npz; reactions whose coefficient the switch changes in cell 0:", d, r[0]["rates"][d], r0[0]["rates"][d])
+
+
 def main_iterprobe():
     """tests/golden/iter_probe_grain.dat: the reference's own iter_NNNN.dat writer (write_header + disk_save_results_write, src/disk.f90:2745-
     3073) on one cell whose k-th printed field holds k + k/1000 (ref_driver, dump_iter_file = 1): pins names, order, widths and formats."""
@@ -430,15 +446,34 @@ def main_shielding():
     print("wrote shielding.npz")
 
 
+def main_xray():
+    """tests/golden/xray.npz: the reference's sigma_Xray_Bethell (oracle/_ref/ref_shielding, lines "XR E eps G a") at 256 seeded points,
+    the band edges, and energies outside the table."""
+    rng = np.random.default_rng(20240609)
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_shielding")
+    E = np.r_[10.0 ** rng.uniform(np.log10(0.03), 1.0, 256), [0.03, 0.055, 0.1, 0.284, 1.303, 8.331, 10.0, 0.01, 0.02, 12.0, 30.0]]
+    eps = np.r_[10.0 ** rng.uniform(-3.0, 0.5, 256), np.ones(9), [0.0, 1.0]]
+    G = np.r_[10.0 ** rng.uniform(-13.0, -11.0, 256), np.full(10, 2.8e-12), [0.0]]
+    a = 10.0 ** rng.uniform(-6.0, -4.5, E.size)
+    inp = "".join("XR %.17e %.17e %.17e %.17e\n" % t for t in zip(E, eps, G, a))
+    out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.split()
+    np.savez_compressed(os.path.join(HERE, "xray.npz"), E_keV=E, dust_depletion=eps, d2h=G, grain_radius=a, sigma=np.array([float(v) for v in out]))
+    print("wrote xray.npz", len(out))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "shielding":
         main_shielding()
+    elif len(sys.argv) > 1 and sys.argv[1] == "xray":
+        main_xray()
     elif len(sys.argv) > 1 and sys.argv[1] == "policy":
         main_policy()
     elif len(sys.argv) > 1 and sys.argv[1] == "grid64":
         main_grid64()
     elif len(sys.argv) > 1 and sys.argv[1] == "evolT":
         main_evolT()
+    elif len(sys.argv) > 1 and sys.argv[1] == "moeq":
+        main_moeq()
     elif len(sys.argv) > 1 and sys.argv[1] == "iterprobe":
         main_iterprobe()
     else:

@@ -128,7 +128,16 @@ def main():
         e_pts = float(np.max(np.abs(mine - ref) / ref))
         print("Visser table through the compiled reference: nodes max rel %.2e, 2000 random points max rel %.2e" % (e_nodes, e_pts))
         assert e_nodes <= 1e-12 and e_pts <= 1e-12
-    print("wrote data/neufeld_cooling_tables.dat, data/visser2009_co_shielding.dat")
+    # ---- Bethell & Bergin 2011, Table 2: X-ray cross sections per H of gas and dust ---------------------------------------------
+    p = os.path.join(SRC, "load_Bethell_Xray.f90")
+    arrs = arrays_of(p, int_parameters(p))
+    assert arrs["E_r"].shape == (2, 16) and arrs["c_g"].shape == (3, 16) and arrs["c_d"].shape == (3, 16)
+    write_tables(os.path.join(ROOT, "data", "bethell2011_xray_cross.dat"),
+                 ["X-ray photoabsorption cross sections per H nucleus of Bethell & Bergin 2011 (ApJ 740, 7), Table 2, as the reference (rac-2d)",
+                  "tabulates them: 16 energy bands E_r(2, band) [keV], polynomial coefficients c_g(3, band) (gas) and c_d(3, band) (dust) of",
+                  "sigma = 1e-24 cm^2 / E^3 (c1 + c2 E + c3 E^2).  Written by tools/extract_reference_tables.py; arrays in column-major order."],
+                 [("", {"E_r": arrs["E_r"], "c_g": arrs["c_g"], "c_d": arrs["c_d"]})])
+    print("wrote data/neufeld_cooling_tables.dat, data/visser2009_co_shielding.dat, data/bethell2011_xray_cross.dat")
 
 
 if __name__ == "__main__":

@@ -65,8 +65,8 @@ int main() {
   OK(hipDeviceSynchronize());
   hipLaunchKernelGGL(k_calib_read_nt, dim3(waves), dim3(64), 0, 0, buf, nper_slice, 8, out);
   OK(hipDeviceSynchronize());
-  printf("{\"k_calib_read_nt_stream_bytes\": %ld, \"k_calib_read_nt_reread_bytes\": %ld}\n", waves * nper_stream * 8, waves * nper_slice * 8 * 8);
-  printf("{\"k_calib_write_bytes\": %ld, \"k_calib_read_stream_bytes\": %ld, \"k_calib_read_reread_bytes\": %ld, \"reread_footprint_bytes\": %ld}\n",
-         waves * nper_stream * 8, waves * nper_stream * 8, waves * nper_slice * 8 * 8, waves * nper_slice * 8);
+  printf("{\"k_calib_write_bytes\": %ld, \"k_calib_read_stream_bytes\": %ld, \"k_calib_read_reread_bytes\": %ld, \"reread_footprint_bytes\": %ld, "
+         "\"k_calib_read_nt_stream_bytes\": %ld, \"k_calib_read_nt_reread_bytes\": %ld}\n",
+         waves * nper_stream * 8, waves * nper_stream * 8, waves * nper_slice * 8 * 8, waves * nper_slice * 8, waves * nper_stream * 8, waves * nper_slice * 8 * 8);
   return 0;
 }

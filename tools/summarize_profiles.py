@@ -79,12 +79,14 @@ cal = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     known = json.load(open(os.path.join(src, "calib_%s.json" % c)))
     rows = list(counters("calib_" + c).items())
-    names = ["k_calib_write", "k_calib_read_stream", "k_calib_read_reread"]
+    names = ["k_calib_write", "k_calib_read_stream", "k_calib_read_reread", "k_calib_read_nt_stream", "k_calib_read_nt_reread"]
     cal[c] = {n: {"counter_KB": e.get(c, 0.0), "counter_bytes": e.get(c, 0.0) * 1024, "ms": e["ms"]} for n, ((d, k), e) in zip(names, rows)}
     cal["known_bytes"] = known
 fetch_factor = cal["known_bytes"]["k_calib_read_stream_bytes"] / cal["FETCH_SIZE"]["k_calib_read_stream"]["counter_bytes"]
 write_factor = cal["known_bytes"]["k_calib_write_bytes"] / cal["WRITE_SIZE"]["k_calib_write"]["counter_bytes"]
 reread_factor = cal["known_bytes"]["k_calib_read_reread_bytes"] / cal["FETCH_SIZE"]["k_calib_read_reread"]["counter_bytes"]
+nt_factor = (cal["known_bytes"]["k_calib_read_nt_stream_bytes"] / cal["FETCH_SIZE"]["k_calib_read_nt_stream"]["counter_bytes"]
+             if "k_calib_read_nt_stream" in cal["FETCH_SIZE"] else None)
 ks = {}  # the pass's solver kernels together: k_solve, then k_solve_team_resume (k_solve_team alongside when cost hints are in place)
 for k, a in allc.items():
     if k.startswith("k_solve"):
@@ -97,9 +99,10 @@ hbm = ks.get("FETCH_SIZE", 0.0) * 1024 * fetch_factor + ks.get("WRITE_SIZE", 0.0
 out = {
     "launch": "bench.py --warmup 0 --steps 1 --no-cpu-baseline (default workload, one k_solve launch in queue order); rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes",
     "calibration": {"method": "tools/pmc_calib: 3072 waves, 8 B per lane raw buffer loads/stores (the solver's access pattern), known byte counts",
-                    "fetch_factor_streamed_once": fetch_factor, "fetch_factor_reread_8x_1.2GB_footprint": reread_factor, "write_factor": write_factor, "raw": cal},
+                    "fetch_factor_streamed_once": fetch_factor, "fetch_factor_reread_8x_1.2GB_footprint": reread_factor, "fetch_factor_nt_loads": nt_factor, "write_factor": write_factor, "raw": cal},
+    "what_the_counters_see": "FETCH_SIZE / WRITE_SIZE count what crosses L2 towards the fabric: Infinity-Cache (MALL) hits as well as HBM -- fabric traffic, an upper bound of the HBM bytes",
     "FETCH_SIZE_KB": ks.get("FETCH_SIZE"), "WRITE_SIZE_KB": ks.get("WRITE_SIZE"), "cell_steps": steps,
-    "hbm_bytes_corrected": hbm, "algorithmic_bytes": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "fabric_bytes_corrected": hbm, "hbm_bytes_corrected": hbm, "algorithmic_bytes": bench["roofline"]["algorithmic_bytes_per_launch"],
     "bytes_per_cell_step_corrected": hbm / steps, "ratio_to_algorithmic": hbm / bench["roofline"]["algorithmic_bytes_per_launch"],
     "kernel_ms_under_profiler": ks.get("ms_per_pass"),
     "workload": {"name": "grid", "network": "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "cells_per_gpu": bench["config"]["cells_per_gpu"]},
