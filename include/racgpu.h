@@ -61,7 +61,7 @@ typedef struct racgpu_params {
   double special_gH_E_diff;     /* %special_gH_E_diff (default 225)                        */
   int32_t mxstep_per_interval;  /* %mxstep_per_interval -> DLSODES MXSTEP (IWORK(6))       */
   int32_t steps_reset_solver;   /* %steps_reset_solver: ISTATE=1 every this many records   */
-  int32_t H2_form_use_moeq;     /* src/chemistry.f90:876-881: gH + gH by the rate equation's steady state */
+  int32_t H2_form_use_moeq;     /* must be 0 for the integrator (error otherwise); racgpu_rates honours it (src/chemistry.f90:876-881) */
   int32_t evol_dust_size;       /* must be 0 (error otherwise)                             */
   int32_t use_special_gH_mobi;  /* %use_special_gH_mobi                                    */
   int32_t tol_policy_j;         /* j of chem_set_solver_flags_alt(j) (src/chemistry.f90:205); 1 = as configured */

@@ -971,7 +971,7 @@ static void cfode_bdf(DevParams &P) { // BDF method coefficients, orders 1..5 (D
   }
 }
 
-static void check_moeq(const racgpu_network *h, const DevParams &P);
+static void check_moeq(const racgpu_network *h, const DevParams &P, bool rates_only);
 static DevParams to_dev(const racgpu_params *p) {
   if (p->evol_dust_size) throw std::runtime_error("evol_dust_size = .true. is not implemented");
   if (!(p->dt_first_step > 0.0) || !(p->ratio_tstep > 1.0) || !(p->t_max > 0.0)) throw std::runtime_error("need dt_first_step > 0, ratio_tstep > 1, t_max > 0");
@@ -1194,7 +1194,7 @@ int racgpu_rates(racgpu_network *h, const racgpu_params *p, const double *cells,
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    check_moeq(h, P, true); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dr(rates, (size_t)ncell * h->dn.nR * 8, RACGPU_MEM_HOST, false);
     hipLaunchKernelGGL(k_rates, dim3((unsigned)ncell), dim3(64), 0, h->stream, h->dn_dev, h->dp_dev, (const double *)dc.d, (double *)dr.d, (double *)nullptr);
@@ -1209,7 +1209,7 @@ int racgpu_rhs(racgpu_network *h, const racgpu_params *p, const double *cells, i
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    check_moeq(h, P, false); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
@@ -1228,7 +1228,7 @@ int racgpu_jac_csc(racgpu_network *h, const racgpu_params *p, const double *cell
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    check_moeq(h, P, false); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
@@ -1247,7 +1247,7 @@ int racgpu_newton_solve(racgpu_network *h, const racgpu_params *p, const double 
   return guarded([&] {
     h->upload();
     DevParams P = to_dev(p);
-    check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+    check_moeq(h, P, false); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream)); // P lives on this stack frame
     const size_t nS = h->dn.nS;
     DevBuf dc(cells, (size_t)ncell * RACGPU_NPAR * 8, RACGPU_MEM_HOST, true), dy(y, ncell * nS * 8, RACGPU_MEM_HOST, true),
@@ -1430,13 +1430,17 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
 
 static void ensure_hc(racgpu_network *h) { if (!h->hc_dev) h->upload_hc(); }
 
-static void check_moeq(const racgpu_network *h, const DevParams &P) {
+// H2_form_use_moeq = .true.: the RATE COEFFICIENT branch (src/chemistry.f90:876-881) is built and pinned; chem_ode_f / chem_ode_jac then treat
+// gH + gH as H + gH with extra terms on H and gH outside the declared sparsity structure (src/disk.f90:4625-4630, 4828-4840): not built, so
+// every entry point that integrates or evaluates f / J refuses the switch instead of running the rate-equation form with the other coefficient
+static void check_moeq(const racgpu_network *h, const DevParams &P, bool rates_only) {
+  if (P.h2_moeq && !rates_only) throw std::runtime_error("H2_form_use_moeq = .true. is not implemented beyond the rate coefficients (see DESIGN.md, out of scope rows)");
   if (P.h2_moeq && h->dn.moeq_r61 == -2)
     throw std::runtime_error("H2_form_use_moeq: the network's adsorption reaction of H and desorption reaction of gH must precede its gH + gH reaction");
 }
 
 static void push_params(racgpu_network *h, const DevParams &P) {
-  check_moeq(h, P); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
+  check_moeq(h, P, false); HIP_OK(hipMemcpyAsync(h->dp_dev, &P, sizeof P, hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream)); // P lives on the caller's stack frame
 }
 

@@ -2,6 +2,7 @@
 species bookkeeping, tolerance policy and symbolic factorisation agree with the reference fixtures.
 No compute entry point is called here; without a GPU they must fail loudly, which is also checked."""
 import ctypes
+import importlib
 import os
 import re
 
@@ -121,3 +122,36 @@ def test_per_cell_tmax_orbit_rule(racgpu):
     assert t[1] == 1e2                                                           # floor t_min = 100 yr
     assert t[2] == 1e6                                                           # capped by t_max0
     assert np.all(racgpu.cells.tmax_this(np.array([omega_1au]), t_max0=3e5, use_fixed_tmax=True) == 3e5)
+
+
+def test_multi_gpu_dealing_rule_is_a_balanced_permutation(racgpu):
+    """racgpu_multi_deal (host only): what racgpu_multi_calc_cells does before the devices start -- every cell gets one owner and one
+    position, device batches differ by at most one cell, positions are 0..n_d-1 per device; with cost hints the cells go round-robin by
+    descending cost (sweep.interleaved_order's rule), without them round-robin in cell order; merging by (owner, position) restores the
+    caller's order."""
+    sweep = importlib.import_module("rac-2d_amd.sweep")
+    rng = np.random.default_rng(5)
+    for ndev, ncell in ((1, 7), (2, 9), (3, 10), (8, 20000), (4, 3)):
+        for cost in (None, rng.uniform(1.0, 100.0, ncell)):
+            owner, pos = racgpu.multi_deal(ndev, ncell, cost)
+            assert owner.min() >= 0 and owner.max() < ndev
+            counts = np.bincount(owner, minlength=ndev)
+            assert counts.max() - counts.min() <= 1
+            for d in range(ndev):
+                assert sorted(pos[owner == d]) == list(range(counts[d]))
+            order = np.arange(ncell) if cost is None else np.argsort(-cost, kind="stable")
+            np.testing.assert_array_equal(owner[order], np.arange(ncell) % ndev)       # k-th costliest cell -> device k mod ndev
+            np.testing.assert_array_equal(pos[order], np.arange(ncell) // ndev)        # ... as its (k div ndev)-th cell
+            if cost is not None:  # the same sets as the torch.distributed path deals (rank r: cells r, r + world, ... of the cost ranking)
+                il = sweep.interleaved_order(cost, ndev)
+                for d in range(ndev):
+                    lo, hi = sweep.partition(ncell, ndev, d)
+                    assert set(il[lo:hi]) == set(np.nonzero(owner == d)[0])
+            # merge: per-device result rows back into cell order
+            rows = [np.full((counts[d], 2), -1.0) for d in range(ndev)]
+            for c in range(ncell):
+                rows[owner[c]][pos[c]] = (c, 10.0 * c)
+            merged = np.array([rows[owner[c]][pos[c]] for c in range(ncell)])
+            np.testing.assert_array_equal(merged[:, 0], np.arange(ncell))
+    with pytest.raises(racgpu.RacgpuError):
+        racgpu.multi_deal(0, 5)

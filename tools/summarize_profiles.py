@@ -50,6 +50,19 @@ if f:
         for r in rd:
             if r["Kernel_Name"].startswith("k_"):
                 w.writerow([r[k].split("(")[0] if k == "Kernel_Name" else r[k] for k in keep] + ["%.3f" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)])
+for mode in ("evolT", "sweep"):  # kernel stats of the two other bench lines
+    f = one("stats_%s/*/*kernel_stats.csv" % mode)
+    if f:
+        rows = list(csv.reader(open(f)))
+        with open(os.path.join(dst, pre + "_kernel_stats_%s_bench.csv" % mode), "w", newline="") as o:
+            w = csv.writer(o)
+            w.writerow(rows[0])
+            for r in rows[1:]:
+                if r and r[0].startswith("k_"):
+                    w.writerow(r)
+    p = os.path.join(src, "bench_stats_%s.json" % mode)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(dst, "%s_bench_%s_under_rocprof_stats.json" % (pre, mode)))
 for name in ("bench_stats", "bench_pmc_FETCH_SIZE", "bench_pmc_WRITE_SIZE", "bench_pmc_sq1"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and os.path.getsize(p) > 0:
