@@ -181,6 +181,7 @@ static_assert(sizeof(Parked) <= kParkWords * sizeof(double), "Parked outgrew its
 struct ColumnAcc { double N_H2, N_H2O, N_OH, N_CO; };
 static __shared__ volatile ColumnAcc g_col;
 static __shared__ volatile ColumnAcc g_ray; // the same towards the star, for the cell being solved
+static __shared__ double g_rec[RACGPU_NPAR + kNHC]; // k_solve_T: the cell record and the heating/cooling record of the cell being solved
 
 template <int TEAM, bool RESUME, bool COLUMN = false, bool ET = false>
 RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, const SolveArgs &A, double *lds) {
@@ -321,7 +322,12 @@ RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, co
       dev_mark(c, 1);
       { double rT, aT; dev_tolerances(N, P, A.tolj ? A.tolj[cell] : P.tol_j, cp[RACGPU_P_D2H], c.rtol, c.atol, rT, aT, lane); g_wc.rT = rT; g_wc.aT = aT; }
       if constexpr (ET) { // set_initial_condition_4solver (src/disk.f90:2066-2073): y(NEQ) = Tgas; T evolves when the cell gains energy
-        c.cell = cp; c.hcrec = A.hc + (size_t)cell * kNHC;
+        // the two records go to LDS once per cell: f(y) reads ~100 of their fields one after the other (dev_rates' header, the 28 terms), and
+        // every one was a dependent global load of 1-2 us under the kernel's own traffic
+        if (lane < RACGPU_NPAR) g_rec[lane] = cp[lane];
+        if (lane < kNHC) g_rec[RACGPU_NPAR + lane] = A.hc[(size_t)cell * kNHC + lane];
+        wave_sync();
+        c.cell = const_cast<const double *>(g_rec); c.hcrec = const_cast<const double *>(g_rec) + RACGPU_NPAR;
         const int j = A.tolj ? A.tolj[cell] : P.tol_j;
         g_T.y = cp[RACGPU_P_TGAS]; g_T.savf = 0.0; g_T.acor = 0.0; g_T.ewt = 0.0; g_T.rtol = g_wc.rT; g_T.atol = g_wc.aT;
         for (int k = 0; k < 6; ++k) g_T.yh[k] = 0.0;

@@ -23,9 +23,9 @@
 !   <out_prefix>.bin : direct-access records in the layout of the reference's chemical_data_iter_NNNN.bin
 !                      (record i = cell i = abundances(nSpecies), col_den_toStar(10), col_den_toISM(10), all f64;
 !                      reference src/data_dump.f90:88-162; the 20 column densities belong to the caller: zeros)
-!   <out_prefix>.dat : one row per cell: t_final, quality, NST, local iterations used, R_H2_form_rate_coeff, n_mol_on_grain (the two
-!                      fields of the cell record the path writes), then abundances in ES14.5E3 under an A14 header
-!                      (the trailing columns of the reference's iter_NNNN.dat, src/disk.f90:2749-2750, 3072)
+!   <out_prefix>.dat : the reference's iter_NNNN.dat (write_header + disk_save_results_write, src/disk.f90:2745-3073): '!' + 6 integer and
+!                      142 real columns + the abundances, one row per cell; columns of subsystems outside this path are zero
+!   <out_prefix>.counters : per cell NST, local iterations used, NERR (no counterpart in the reference's file)
 !   with flag_chem_evol_save = .true. in the namelist, per cell i also
 !   <out_prefix>_cellNNNNNN_<chem_evol_save_filename> : the time series chem_evol_solve writes while it integrates
 !                      (reference src/chemistry.f90:404-413, 476-478): header '! Time', species names, 'Tgas' in A14,
@@ -47,7 +47,9 @@ program racgpu_host
   type(c_ptr) :: net
   type(racgpu_params_t) :: p
   integer(c_int32_t) :: nS, nR, nnzJ, nzl, nzu
-  integer :: fu, ios, ncell, i, k, rc, reclen, n_record, nrr
+  integer :: fu, ios, ncell, i, k, rc, reclen, n_record, nrr, i_gH, i_H
+  real(c_double), allocatable :: vrow(:)
+  include 'iter_columns.inc'
   real(c_double), allocatable, target :: record(:, :, :), touts(:, :)
   type(c_ptr) :: prec, ptouts
   character(len=16) :: tag
@@ -227,13 +229,53 @@ program racgpu_host
     write(fu, rec=i) y(:, i), zeros20
   end do
   close(fu)
+  ! <out_prefix>.dat: the reference's iter_NNNN.dat (write_header + disk_save_results_write, src/disk.f90:2745-3073): "!" + 6 integer and
+  ! 142 real columns + the abundances; the columns that belong to subsystems outside this path (geometry, photon counters, masses, fluxes)
+  ! are written as the reference writes them for a cell those subsystems have not touched: zero
   open(newunit=fu, file=trim(prefix) // '.dat', status='replace')
-  write(fmt, '("(", I4, "A14)")') nS + 7
-  write(fu, fmt) '  t_final     ', '  quality     ', '  NST         ', '  local_iter  ', '  R_H2_form   ', '  n_mol_grain ', &
-                 '  Tgas        ', (adjustr(names(i) // '  '), i = 1, nS)
-  write(fmt, '("(ES14.5E3, 3I14, ", I4, "ES14.5E3)")') nS + 3
+  write(fmt, '("(A1, A4, A5, ", I4, "A14)")') 4 + n_iter_real + nS
+  write(fu, fmt) '!', 'cvg', 'qual', adjustr('cr_count      '), adjustr('abc_dus       '), adjustr('scc_HI        '), adjustr('abc_wat       '), &
+                 (adjustr(iter_real_names(i) // '      '), i = 1, n_iter_real), ('  ' // names(i), i = 1, nS)
+  write(fmt, '("(2I5, 4I14, ", I4, "ES14.5E3)")') n_iter_real + nS
+  allocate(vrow(n_iter_real))
+  i_gH = 0; i_H = 0
+  do i = 1, nS
+    if (trim(names(i)) .eq. 'gH') i_gH = i
+    if (trim(names(i)) .eq. 'H') i_H = i
+  end do
   do i = 1, ncell
-    write(fu, fmt) t_final(i), quality(i), int(stats(1, i)), int(stats(18, i)), cell_out(1, i), cell_out(2, i), cell_out(4, i), y(:, i)
+    vrow = 0D0
+    vrow(icol('t_final')) = t_final(i);  vrow(icol('n_gas')) = cells(3, i);   vrow(icol('Tgas')) = cell_out(4, i)
+    vrow(icol('Tdust')) = cells(2, i);   vrow(icol('ndust_t')) = cells(6, i); vrow(icol('sigd_av')) = cells(5, i)
+    vrow(icol('d2gnum')) = cells(7, i);  vrow(icol('Av_ISM')) = cells(13, i); vrow(icol('Av_Star')) = cells(14, i)
+    vrow(icol('UV_G0_I')) = cells(15, i); vrow(icol('UV_G0_S')) = cells(16, i)
+    vrow(icol('LyANF0')) = cells(19, i); vrow(icol('LyAG0_a')) = cells(19, i) / 6D7   ! G0_Lya_atten (src/disk.f90:1880)
+    vrow(icol('zeta_X')) = cells(11, i); vrow(icol('Ncol_I')) = cells(12, i)
+    vrow(icol('f_H2_I')) = cells(20, i); vrow(icol('f_CO_I')) = cells(21, i); vrow(icol('f_H2O_I')) = cells(22, i); vrow(icol('f_OH_I')) = cells(23, i)
+    vrow(icol('f_H2_S')) = cells(24, i); vrow(icol('f_CO_S')) = cells(25, i); vrow(icol('f_H2O_S')) = cells(26, i); vrow(icol('f_OH_S')) = cells(27, i)
+    vrow(icol('nsit_gr')) = cells(8, i); vrow(icol('nmol_gr')) = cell_out(2, i)
+    if (i_gH .gt. 0) then   ! get_H2_form_rate (src/disk.f90:4302-4315)
+      vrow(icol('R_H2_fo')) = cell_out(1, i) * y(i_gH, i) * y(i_gH, i) * cells(3, i)
+    else if (i_H .gt. 0) then
+      vrow(icol('R_H2_fo')) = cell_out(1, i) * y(i_H, i) * cells(3, i)
+    end if
+    if (allocated(hc)) then
+      do k = 1, 4
+        write(tag, '(I1)') k
+        vrow(icol('Tdust' // tag(1:1))) = hc(20 + k, i); vrow(icol('ndust_' // tag(1:1))) = hc(16 + k, i)
+        vrow(icol('sigdus_' // tag(1:1))) = hc(12 + k, i); vrow(icol('egain_d' // tag(1:1))) = hc(24 + k, i)
+      end do
+      vrow(icol('egain_d')) = hc(1, i); vrow(icol('deplet')) = hc(10, i); vrow(icol('Ncol_S')) = hc(2, i)
+      vrow(icol('w_Kep')) = hc(5, i);   vrow(icol('dv_turb')) = hc(6, i); vrow(icol('l_coher')) = hc(7, i)
+    end if
+    write(fu, fmt) 0, quality(i), 0, 0, 0, 0, vrow, y(:, i)
+  end do
+  close(fu)
+  ! <out_prefix>.counters: what the engine adds per cell (no counterpart in the reference's file)
+  open(newunit=fu, file=trim(prefix) // '.counters', status='replace')
+  write(fu, '(A)') '!       NST    local_iter          NERR'
+  do i = 1, ncell
+    write(fu, '(3I14)') int(stats(1, i)), int(stats(18, i)), int(stats(5, i))
   end do
   close(fu)
   if (chemsol_params%flag_chem_evol_save) then
@@ -251,4 +293,18 @@ program racgpu_host
     end do
   end if
   call racgpu_network_destroy(net)
+contains
+  integer function icol(name)
+    character(len=*), intent(in) :: name
+    integer :: k
+    icol = 0
+    do k = 1, n_iter_real
+      if (trim(iter_real_names(k)) .eq. trim(name)) then
+        icol = k
+        return
+      end if
+    end do
+    write(*, '(2A)') 'racgpu_host: unknown iter_NNNN.dat column ', name
+    stop 1
+  end function icol
 end program racgpu_host

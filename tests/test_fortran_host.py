@@ -29,10 +29,21 @@ def test_fortran_host_matches_reference(tmp_path, racgpu):
         ref = g["yend"][c][:nS]
         floor = major_relerr(g["yend_ulp"][c][:nS], ref)
         assert major_relerr(rec[c, :nS], ref) <= max(1e-4, 3 * floor)
+    # <out>.dat is the reference's iter_NNNN.dat: header byte for byte what analysis.write_iter_dat (pinned to the reference's own writer,
+    # tests/test_analysis.py) writes for this network, rows parsed by the reference reader's rules
+    A = racgpu.analysis
     rows = open(tmp_path / "out.dat").read().splitlines()
-    assert len(rows) == 3 and len(rows[0]) == 14 * (nS + 7)
-    hdr = [rows[0][14 * k:14 * (k + 1)].strip() for k in range(nS + 7)]
-    assert hdr[6] == "Tgas" and hdr[7:] == list(g["species"])
+    assert len(rows) == 3
+    cols = {k: np.zeros(2) for k in A.ITER_INT_COLUMNS + A.ITER_REAL_COLUMNS}
+    A.write_iter_dat(tmp_path / "py.dat", list(g["species"]), cols, np.zeros((2, nS)))
+    assert rows[0].rstrip() == open(tmp_path / "py.dat").read().splitlines()[0].rstrip()
+    d = A.load_iter_dat(tmp_path / "out.dat")
+    assert len(d) == 148 + nS
+    np.testing.assert_allclose(d["n_gas"], cells[:, racgpu.cells.P_NGAS], rtol=1e-5)
+    np.testing.assert_allclose(d["Tgas"], cells[:, racgpu.cells.P_TGAS], rtol=1e-5)
+    np.testing.assert_allclose(d["f_CO_S"], cells[:, racgpu.cells.P_FSS_STAR_CO], rtol=1e-5)
+    np.testing.assert_allclose(np.array([d[nm] for nm in g["species"]]).T, rec[:, :nS], rtol=1.1e-5, atol=1e-290)
+    assert (d["t_final"] > 0).all() and (d["qual"] == 0).all()
     # restart from the .bin just written (the reference's use_backup_chemical_data path), local-iteration loop on: cells
     # that finished with quality 0 stay as they are handed in (t0 = 0 again, so this is a second full run from the end state)
     out2 = subprocess.run([HOST, os.path.join(ROOT, "tests", "fortran_host", "configure_chemistry.dat"), str(tmp_path / "cells.txt"),
@@ -40,8 +51,8 @@ def test_fortran_host_matches_reference(tmp_path, racgpu):
     assert out2.returncode == 0 and "Abundances taken from" in out2.stdout, out2.stdout + out2.stderr
     rec2 = np.fromfile(tmp_path / "out2.bin", dtype=np.float64).reshape(2, nS + 20)
     assert np.isfinite(rec2).all() and rec2.shape == rec.shape
-    row2 = open(tmp_path / "out2.dat").read().splitlines()[1]
-    assert int(row2[14 * 3:14 * 4]) == 1  # one local iteration sufficed
+    row2 = open(tmp_path / "out2.counters").read().splitlines()[1]
+    assert int(row2.split()[1]) == 1  # one local iteration sufficed
 
 
 @pytest.mark.gpu
@@ -148,5 +159,5 @@ def test_fortran_host_with_the_gas_temperature_evolving(tmp_path, racgpu):
         ref, twin = g["yend"][c], g["yend_ulp"][c]
         floor = max(major_relerr(twin[:nS], ref[:nS]), abs(twin[nS] - ref[nS]) / ref[nS])
         assert major_relerr(rec[k, :nS], ref[:nS]) <= max(1e-4, 3 * floor)
-        T = float(rows[1 + k][14 * 6:14 * 7])
+        T = float(racgpu.analysis.load_iter_dat(tmp_path / "out.dat")["Tgas"][k])
         assert abs(T - ref[nS]) <= max(1e-4, 3 * floor) * ref[nS] + 5e-6 * ref[nS]  # (ES14.5E3: six digits)
