@@ -14,7 +14,7 @@ constexpr int K_NONE_ = 0, K_TWO_ = 1, K_ONE_ = 2, K_SURF_ = 3, K_SURF75_ = 4, K
 
 // extents of column j in the U, L and P storage; ur = end of the U entries with rows < ns (the pivots applied through
 // LDS); [d0, d1) = the column's slice of the pivot descriptor stream
-struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, j, pad[6]; }; // j = the column this work item factors
+struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, j, o0, o1, pad[4]; }; // j = the column this work item factors
 #ifndef RG_JAC_UNROLL
 #define RG_JAC_UNROLL 8
 #endif
@@ -24,6 +24,13 @@ struct alignas(64) LuCol { int u0, u1, lc0, lc1, p0, p1, ur, d0, d1, j, pad[6]; 
 #ifndef RG_LU_DEPTH
 #define RG_LU_DEPTH 6
 #endif
+#ifndef RG_LU_OPS
+#define RG_LU_OPS 0 // 0: one operation per pivot (DevNet::Udesc); 1: the pivots k < ns of a column as entry-parallel operations (DevNet::Uop):
+                    // 30 % fewer instructions and a third fewer LDS atomics, 6-8 % SLOWER (profiles/r3_tuning.txt): kept as a measured experiment
+#endif
+#ifndef RG_LU_OPS_DEPTH
+#define RG_LU_OPS_DEPTH 4 // operations whose L values and rows are in flight
+#endif
 // depths and group sizes below: measured on the configs[2] scan, round 2 (profiles/r2_tuning.txt)
 constexpr int kJacUnroll = RG_JAC_UNROLL; // rows of the Jacobian term stream per unrolled step (the stream is padded to a multiple)
 constexpr int kSweepDepth = RG_SWEEP_DEPTH; // chunks of a triangular-solve stream in flight; the schedules are padded to a multiple
@@ -32,6 +39,7 @@ constexpr int kSweepDepth = RG_SWEEP_DEPTH; // chunks of a triangular-solve stre
 #endif
 constexpr int kTeam = RG_TEAM; // waves of a team (k_solve_team: the cells that would otherwise set the length of a pass)
 constexpr int kLuDepth = RG_LU_DEPTH; // L columns in flight per wave in the LDS pivot loop
+constexpr int kLuOpsDepth = RG_LU_OPS_DEPTH;
 
 struct DevNet {
   int nS, nR, npad;          // npad = nS rounded up to 64
@@ -73,6 +81,12 @@ struct DevNet {
   // (the pivot opens a new level within column j, or is the first of a fetch of 60); 32-52 2*start; 53-61 8*(len-1) (0 for
   // len 0) -- everything the pivot loop needs as byte offsets.
   const unsigned long long *Udesc;
+  // RG_LU_OPS: the same pivots as entry-parallel operations.  Per column j one slice [o0, o1) of operations (LuCol::o0/o1); an operation is 64
+  // words, one per lane: (position in L) << 16 | pivot column k (bit 12 of the first word: the next operation continues the level), for up to 64 (pivot, L entry) pairs of ONE dependency level of the
+  // column (levels in order, pivots of a level in U storage order, an L column's entries in storage order; an L column may straddle
+  // operations).  Lanes past the end of a level name the spare entries behind L (nzl + lane), whose row list entries name the spare LDS
+  // doubles behind the work column: nothing is masked.
+  const uint32_t *Uop;
   const LuCol *lucol;        // [nwork+2] the LU's work list (engine.hip, upload): columns with pivots, then the trailing block
   int nwork_sparse, nwork;   // work items with j < ns / in all
   // k_solve_team: the work items with j < ns again, one list per wave of a team, ordered by dependency level (engine.hip, upload)

@@ -715,6 +715,8 @@ void racgpu_network::upload() {
     std::vector<uint16_t> perm(S.perm.begin(), S.perm.end()), Lrow(S.Lrow.begin(), S.Lrow.end()), Urow(S.Urow.begin(), S.Urow.end()),
         Prow(S.Prow.begin(), S.Prow.end());
     Lrow.resize(Lrow.size() + 64, 0); Urow.resize(Urow.size() + 64, 0); // the LU prefetch reads up to 64 entries past a column
+    // (RG_LU_OPS: the 64 entries behind L's row list name the spare LDS doubles behind the work column, one per lane)
+    for (int q = 0; q < 64; ++q) Lrow[S.Lrow.size() + q] = (uint16_t)(((nS + 1) & ~1) + q);
     Prow.resize(Prow.size() + 64, 0);
     dn.perm = up(perm); dn.Lrow = up(Lrow); dn.Urow = up(Urow); dn.Prow = up(Prow);
     {
@@ -754,6 +756,8 @@ void racgpu_network::upload() {
       // pattern being exactly P's (leaf_diag: position of P(j,j) | j<<32; leaf_ent: position in P | position in L
       // << 20 | j << 40).
       std::vector<unsigned long long> ud, leaf_diag, leaf_ent;
+      std::vector<uint32_t> uop;
+      if ((size_t)S.nzl + 64 > 0xffff) throw std::runtime_error("LU layout: L storage too large for the 16-bit positions of the pivot operations");
       std::vector<LuCol> lc;
       int nwork_sparse = 0;
       for (int j = 0; j < nS; ++j) {
@@ -795,11 +799,32 @@ void racgpu_network::upload() {
           }
         }
         c.d1 = (int)ud.size();
+        // the same pivots as entry-parallel operations (device_tables.hpp, Uop; built only for RG_LU_OPS = 1)
+        c.o0 = (int)(uop.size() / 64);
+        if (RG_LU_OPS) {
+          // (bit 12 of an operation's first word: the operation after it belongs to the same level, so its multipliers may be read ahead)
+          size_t level_first_op = uop.size() / 64;
+          auto flush = [&]() {
+            while (uop.size() % 64) { const uint32_t lane = (uint32_t)(uop.size() % 64); uop.push_back(((uint32_t)(S.nzl + lane) << 16) | 0u); }
+            const size_t end_op = uop.size() / 64;
+            for (size_t o = level_first_op; o + 1 < end_op; ++o) uop[o * 64] |= 0x1000u;
+            level_first_op = end_op;
+          };
+          for (int q = S.Ucolptr[j]; q < c.ur; ++q) {
+            if (S.Ugrp[q] && q > S.Ucolptr[j]) flush(); // a new level: its multipliers are final only after the operations before it
+            const int k = S.Urow[q];
+            for (int t = S.Lcolptr[k]; t < S.Lcolend[k]; ++t) uop.push_back(((uint32_t)t << 16) | (uint32_t)k); // (k <= 1022: build_symbolic)
+          }
+          flush();
+        }
+        c.o1 = (int)(uop.size() / 64);
         lc.push_back(c);
         if (j < S.ns) ++nwork_sparse;
       }
       ud.resize(ud.size() + 64, 0ull);
       dn.Udesc = up(ud);
+      for (int q = 0; q < 64 * (4 * RG_LU_OPS_DEPTH); ++q) uop.push_back(((uint32_t)(S.nzl + q % 64) << 16) | 0u); // spare operations: the prefetch runs ahead
+      dn.Uop = up(uop);
       dn.nwork_sparse = nwork_sparse; dn.nwork = (int)lc.size();
       dn.nleaf = (int)leaf_diag.size(); dn.nleaf_ent = (int)leaf_ent.size();
       leaf_diag.resize(leaf_diag.size() + 64, 0ull); leaf_ent.resize(leaf_ent.size() + 64, 0ull);

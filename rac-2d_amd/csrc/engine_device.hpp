@@ -466,7 +466,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
 #define RG_EXP_BL bL
 #endif
   const RG_GLOBAL int *cols = gptr(reinterpret_cast<const int *>(N.lucol)); // 16 ints per column (team mode: first the wave's own list)
-  auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; r.j = c[9]; return r; };
+  auto load_col = [&](int j) { const RG_GLOBAL int *c = cols + 16 * j; LuCol r; r.u0 = c[0]; r.u1 = c[1]; r.lc0 = c[2]; r.lc1 = c[3]; r.p0 = c[4]; r.p1 = c[5]; r.ur = c[6]; r.d0 = c[7]; r.d1 = c[8]; r.j = c[9]; r.o0 = c[10]; r.o1 = c[11]; return r; };
   for (int i = lane; i < n; i += 64) w[i] = 0.0; // the work column is kept all-zero between columns
   lds_sync();
   // the trailing columns are stored back to back in index order, so their starts have closed forms (scalar ALU)
@@ -499,6 +499,60 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
   // so the wave never waits for them either; the LDS executes one wave's operations in issue order, which is what
   // makes the next level's read see them.  L columns are loaded kLuDepth-1 pivots ahead into register sets
   // with static indices (the loop is unrolled by the depth).
+#if RG_LU_OPS
+  // Entry-parallel form (device_tables.hpp, Uop): an operation is up to 64 (pivot k, entry of L(:,k)) pairs of ONE level of the column, one per
+  // lane: the lane fetches its L value and row through the position its table word names, its multiplier w[k] from LDS, and adds -l * w[k] to
+  // w[row] (LDS atomic, no return).  The LDS executes a wave's operations in issue order, so the reads of a level see every update of the levels
+  // before it; lanes of one operation that hit the same row are added one after the other by the LDS (same order every time).  6 159 pivots of
+  // on average 30 entries become 4 093 operations of on average 45: about 17 instructions per operation against 24 per pivot.  Table words
+  // are two turns of the register sets ahead, L values and rows one turn.
+  const rsrc_t bUop = mkbuf(N.Uop);
+  const int l4 = lane * 4;
+  auto rect_phase = [&](int widx, double *wv) { // widx: position in the work list; the column is cur.j afterwards
+    cur = nxc; cu_fu = nx_fu; cu_fl = nx_fl;
+    const double pv = nx_pv; const int pr = nx_pr;
+    nxc = nx2; nx2 = load_col(widx + 2);
+    prefetch_col();
+    if (lane < cur.p1 - cur.p0) wv[pr] = pv;
+    for (int q = cur.p0 + 64 + lane; q < cur.p1; q += 64) wv[bload_u16(bProw, q * 2, 0)] = pload_f64(bP, q * 8, 0); // rare: > 64 entries
+    lds_sync();
+    RG_TICK(c_scatter)
+    constexpr int D = kLuOpsDepth;
+    const int nop = cur.o1 - cur.o0;
+    if (nop > 0) {
+      uint32_t ta[D], tb[D]; // table words: ta of the operations whose values are in flight, tb of the turn after
+      double l[D]; uint16_t i[D];
+      const int o256 = cur.o0 * 256;
+#pragma unroll
+      for (int s = 0; s < D; ++s) ta[s] = bload_u32(bUop, l4, o256 + s * 256);
+#pragma unroll
+      for (int s = 0; s < D; ++s) tb[s] = bload_u32(bUop, l4, o256 + (D + s) * 256);
+#pragma unroll
+      for (int s = 0; s < D; ++s) { // (position << 16 | k: >> 13 and >> 15 leave the byte offsets of the f64 value and of the u16 row)
+        l[s] = sload_f64(bL, (int)(ta[s] >> 13), 0); i[s] = bload_u16(bLrow, (int)(ta[s] >> 15), 0);
+        __builtin_amdgcn_sched_barrier(0); // keep the issue order: data returns in order
+      }
+      double tvn = 0.0; bool have = false; // the multipliers of the next operation, read ahead when it continues the level
+      for (int t = 0; t < nop; t += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          if (t + s < nop) {
+            double tv;
+            if (have) tv = tvn;
+            else { lds_order(); tv = wv[ta[s] & 0x3ffu]; }
+            have = (__builtin_amdgcn_readfirstlane((int)ta[s]) & 0x1000) != 0; // lane 0's word, bit 12: the next operation belongs to the same level
+            if (have) tvn = wv[ta[(s + 1) % D] & 0x3ffu]; // (before this operation's updates are queued)
+            atomicAdd(&wv[i[s]], -(l[s] * tv));
+          }
+          ta[s] = tb[s];
+          l[s] = sload_f64(bL, (int)(ta[s] >> 13), 0); i[s] = bload_u16(bLrow, (int)(ta[s] >> 15), 0);
+          tb[s] = bload_u32(bUop, l4, o256 + (t + 2 * D + s) * 256);
+        }
+      }
+    }
+    RG_TICK(c_rect)
+  };
+#else
   auto rect_phase = [&](int widx, double *wv) { // widx: position in the work list; the column is cur.j afterwards
     cur = nxc; cu_fu = nx_fu; cu_fl = nx_fl;
     const unsigned long long dq0 = nx_dq;
@@ -561,6 +615,7 @@ RG_DEV bool dev_lu(const DevNet &N, const double *__restrict__ Pv, double *__res
     }
     RG_TICK(c_rect)
   };
+#endif
 
   // U part of the current column with rows < uend_rect: final after the LDS pivots; scaled and stored
   auto store_u = [&](double *wv, int uend) {

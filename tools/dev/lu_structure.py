@@ -53,3 +53,26 @@ for g0 in range(0, n - ns, G):
 print("phase 2: k-visits", vis, " L21 entries read", ent, " pairs", pairs2, " max U12 entries of a panel", mx)
 lenA = L[ns:ns + 64, :ns].sum(0); lenB = L[ns + 64:, :ns].sum(0)
 print("L21 pieces: with A rows %d, with B rows %d, max len A %d B %d" % ((lenA > 0).sum(), (lenB > 0).sum(), lenA.max(), lenB.max()))
+print("---- entry-parallel level ops: per column j, its pivots k < ns by level within the column; one op = up to 64 (pivot, L entry) pairs of one level")
+ops = 0; ents = 0; piv = 0; lev_tot = 0
+hist = []
+for j in range(n):
+    rows_u = np.nonzero(U[:min(j, ns), j])[0] if j > 0 else np.array([], int)
+    if len(rows_u) == 0:
+        continue
+    plev = {}
+    for a in rows_u:
+        l = 0
+        for b in rows_u:
+            if b >= a: break
+            if F[a, b]: l = max(l, plev[b] + 1)
+        plev[a] = l
+    nl = max(plev.values()) + 1
+    lev_tot += nl
+    for l in range(nl):
+        ks = [k for k in rows_u if plev[k] == l]
+        E = int(sum(lenL[k] for k in ks))
+        piv += len(ks); ents += E
+        o = -(-E // 64) if E > 0 else 0
+        ops += o; hist.append(E)
+print("columns with pivots: levels %d, pivots %d, entries %d -> ops %d (now: one op per pivot = %d); mean fill of an op %.1f of 64" % (lev_tot, piv, ents, ops, piv, ents / max(ops, 1)))
