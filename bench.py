@@ -247,7 +247,11 @@ def cpu_baseline_and_parity(cells, sample_idx, network, initial, params, gpu, nS
                   "cells_within_max(1e-4,3*floor)": int((errs <= bound).sum()),
                   "worst_cell": {"cell": int(sample_idx[kw]), "species_index": spec[kw], "err": float(errs[kw]), "floor": float(floors[kw]),
                                  "err_over_bound": float(excess[kw])},
-                  "exceptions": [dict({"cell": int(sample_idx[k]), "species_index": spec[k], "err": float(errs[k]), "floor": float(floors[k])},
+                  # (a cell where either side had an error return runs on with RTOL of the offending species raised tenfold, up to 1e-3, by the
+                  # reference's own policy: the error returns of the GPU, the reference and its twins are listed with each exception)
+                  "exceptions": [dict({"cell": int(sample_idx[k]), "species_index": spec[k], "err": float(errs[k]), "floor": float(floors[k]),
+                                       "error_returns": {"gpu": int(gpu["nerr"][sample_idx[k]]), "reference": int(ref[k]["scalars"][2]),
+                                                         "reference_twins": [int(tw[k]["scalars"][2]) for tw in twins]}},
                                       **({"T_freeze_record": {"gpu": frz[k][0], "reference": frz[k][1]}} if frz else {}))
                                  for k in np.nonzero(errs > bound)[0][:16]],
                   "ended_early_by_the_modelled_run_time_guard": {"cells": [int(sample_idx[k]) for k in np.nonzero(guard)[0]],
@@ -364,6 +368,7 @@ def main():
     # runs of cpu_baseline/parity have it off (their clock is this host's), so cells it ended on the GPU are listed, not compared.
     if netkey == "rate12":
         params.RTOL = 1e-6; params.t_max = 1e7  # BASELINE.json configs[4]
+    hc_h = None
     if args.workload == "grid":
         if args.scaling == "strong" and world > 1:
             full = R.cells.andrews_grid()
@@ -373,7 +378,6 @@ def main():
             cells_h = np.ascontiguousarray(full[order[lo:hi]])
         else:
             cells_h = R.cells.andrews_grid(Md=2e-2 * (1.0 + rank / 16.0))
-        hc_h = None
         if args.evolT:
             if args.scaling == "strong" and world > 1:
                 raise SystemExit("--evolT: weak scaling only")
