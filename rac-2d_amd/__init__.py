@@ -423,9 +423,14 @@ class Network:
         _check(lib().racgpu_heat_reactions(self._h, C.byref(n), _ip(rx), _dp(ht)))
         return rx, ht
 
-    def ode_f_evolT(self, params, cell_records, hc_records, y, jac_border=False):
+    def ode_f_evolT(self, params, cell_records, hc_records, y, jac_border=False, full_rows=False):
         """chem_ode_f with T evolving at y [ncell, nS+1] (last entry Tgas): dict(ydot [ncell, nS+1], terms [ncell, 29]); with
-        jac_border also chem_ode_jac's finite-difference T column [ncell, nS+1] and T row [ncell, 10]."""
+        jac_border also chem_ode_jac's finite-difference T column [ncell, nS+1] and T row [ncell, 10].  full_rows (developer switch,
+        RACGPU_DEBUG_FULL_TROW): every T-row entry by a full evaluation of the 28 terms instead of the blocks its species enters."""
+        if full_rows:
+            os.environ["RACGPU_DEBUG_FULL_TROW"] = "1"
+        else:
+            os.environ.pop("RACGPU_DEBUG_FULL_TROW", None)
         cr = np.ascontiguousarray(cell_records, np.float64).reshape(-1, NPAR)
         n = cr.shape[0]
         hr = np.ascontiguousarray(hc_records, np.float64).reshape(n, NHC)

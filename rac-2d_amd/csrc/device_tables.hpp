@@ -40,6 +40,7 @@ constexpr int kSweepDepth = RG_SWEEP_DEPTH; // chunks of a triangular-solve stre
 constexpr int kTeam = RG_TEAM; // waves of a team (k_solve_team: the cells that would otherwise set the length of a pass)
 constexpr int kLuDepth = RG_LU_DEPTH; // L columns in flight per wave in the LDS pivot loop
 constexpr int kLuOpsDepth = RG_LU_OPS_DEPTH;
+constexpr int kRateTab = 640; // doubles of the LDS table of pow / exp values per distinct exponent / barrier (k_solve_T)
 
 struct DevNet {
   int nS, nR, npad;          // npad = nS rounded up to 64
@@ -53,6 +54,10 @@ struct DevNet {
   const uint8_t *r_flags;          // bit0: first reactant is H2; bit1: first reactant is gH; bit2: type-21 pair has opposite charges
   const uint16_t *r_id3;           // type 21: the non-dust reactant
   const double *r_A, *r_B, *r_C, *r_T0, *r_T1;
+  // itype 5/6: the distinct exponents B and barriers C of the network (rate06+grain: 170 and 278 for 4 191 reactions) and, per reaction,
+  // their indices (ib | ic << 16).  With T evolving every f(y) redoes chem_cal_rates: pow(T/300, B) and exp(-C/T) are then evaluated
+  // once per distinct value into an LDS table and looked up per reaction (dev_rates, tab) -- the same function on the same arguments.
+  const double *r_ub, *r_uc; const uint32_t *r_ibc; int n_ub, n_uc;
   const double *s_mass, *s_vib, *s_Edes;
   const int *dupli_ptr, *dupli_list; // 0-based reaction numbers
   // ---- RHS: one packed row per reaction ----

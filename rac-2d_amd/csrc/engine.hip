@@ -130,8 +130,8 @@ __global__ __launch_bounds__(64) void k_evolT_hooks(const DevNet *__restrict__ N
   if (lane == 0) ydot_out[(size_t)cell * (n + 1) + n] = g_T.savf;
   // the terms once more, this time stored (same inputs: the rate vector is the one dev_f has just computed)
   dev_heating_cooling(N, *(const RG_GLOBAL DevHC *)hc_tab, c.cell, c.hcrec, c.y, g_T.y, c.rates, g_T.rh2, lane, terms_out + (size_t)cell * HC_NTERMS);
-  if (what == 1) {
-    dev_T_border(N, c, 1.0);
+  if (what >= 1) { // (what == 2: the T row by ten full evaluations of the terms, to check the masks of the production path against)
+    dev_T_border(N, c, 1.0, what == 2);
     for (int i = lane; i < n; i += 64) tcol_out[(size_t)cell * (n + 1) + i] = c.Pb[i];
     if (lane == 0) {
       tcol_out[(size_t)cell * (n + 1) + n] = g_T.Pd - 1.0;
@@ -629,6 +629,19 @@ void racgpu_network::upload() {
   dn.r_itype = up(itype); dn.r_re0 = up(re0); dn.r_re1 = up(re1); dn.r_nreac = up(nreac); dn.r_fss = up(fss);
   dn.r_flags = up(flags); dn.r_id3 = up(id3);
   dn.r_A = up(A); dn.r_B = up(B); dn.r_C = up(C); dn.r_T0 = up(T0); dn.r_T1 = up(T1);
+  {
+    std::vector<double> ub, uc;
+    std::vector<uint32_t> ibc(nR, 0);
+    auto index_of = [](std::vector<double> &u, double v) { // (bit pattern: -0.0 and 0.0 stay apart, as pow and exp see them)
+      for (size_t q = 0; q < u.size(); ++q) if (std::memcmp(&u[q], &v, sizeof v) == 0) return (uint32_t)q;
+      u.push_back(v); return (uint32_t)(u.size() - 1);
+    };
+    for (int r = 0; r < nR; ++r) if (itype[r] == 5 || itype[r] == 6) { const uint32_t ib = index_of(ub, B[r]), ic = index_of(uc, C[r]); ibc[r] = ib | (ic << 16); }
+    dn.n_ub = (int)ub.size(); dn.n_uc = (int)uc.size();
+    if (dn.n_ub + dn.n_uc > kRateTab || dn.n_ub > 0xffff || dn.n_uc > 0xffff) { dn.n_ub = dn.n_uc = 0; } // too many distinct values for the LDS table: direct evaluation
+    ub.resize(ub.size() + 64, 0.0); uc.resize(uc.size() + 64, 0.0);
+    dn.r_ub = up(ub); dn.r_uc = up(uc); dn.r_ibc = up(ibc);
+  }
   dn.s_mass = up(h.mass_num); dn.s_vib = up(h.vib_freq); dn.s_Edes = up(h.Edesorb);
   {
     std::vector<int> dl(h.dupli_list);
@@ -1616,7 +1629,7 @@ int racgpu_evolT_hooks(racgpu_network *h, const racgpu_params *p, const double *
         dtr(trow, (size_t)ncell * 10 * 8, RACGPU_MEM_HOST, false);
     h->ensure_workspace((long)ncell, (long)ncell);
     hipLaunchKernelGGL(k_evolT_hooks, dim3((unsigned)ncell), dim3(64), lds_bytes(h->dn), h->stream, h->dn_dev, h->dp_dev, h->ws, (const DevHC *)h->hc_dev,
-                       (const double *)dc.d, (const double *)dh.d, (const double *)dy.d, tcol ? 1 : 0, (double *)dd.d, (double *)dt.d, (double *)dtc.d, (double *)dtr.d);
+                       (const double *)dc.d, (const double *)dh.d, (const double *)dy.d, tcol ? (getenv("RACGPU_DEBUG_FULL_TROW") ? 2 : 1) : 0, (double *)dd.d, (double *)dt.d, (double *)dtc.d, (double *)dtr.d);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(h->stream));
     dd.copy_out(); dt.copy_out(); dtc.copy_out(); dtr.copy_out();

@@ -123,7 +123,8 @@ RG_DEV double dev_branching(int itype, double A, double B, double C, double T0, 
 // Tover (may be null): the gas temperature to use instead of the record's (evolT: chem_ode_f sets chem_params%Tgas = y(NEQ) before
 // it calls chem_cal_rates, reference src/disk.f90:4577-4580)
 RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restrict__ cell, double *__restrict__ rates, int lane,
-                      double *rh2 = nullptr, const double *Tover = nullptr) {
+                      double *rh2 = nullptr, const double *Tover = nullptr, double *tab = nullptr) {
+  // tab (LDS, kRateTab doubles; null: every reaction evaluates its own pow and exp): see DevNet::r_ub
   const double Tgas = Tover ? *Tover : cell[0], Tdust = cell[1], n_gas = cell[2], D2H = cell[6], sites = cell[7];
   const double T300 = Tgas / 300.0;
   const double Tred = cst::kB_SI * Tgas / (cst::eCharge_SI * cst::eCharge_SI * cst::Coulomb_SI / (cell[3] * 1e-2));
@@ -134,12 +135,30 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
   }
   const double sig = cell[4];
   const double cr = cell[9] / cst::CR0 * exp(-cell[11] / cst::CRattenN), xr = cell[10] / cst::CR0;
+  const bool tabbed = tab != nullptr && N.n_ub > 0;
+  if (tabbed) {
+    for (int q = lane; q < N.n_ub; q += 64) tab[q] = pow(T300, gptr(N.r_ub)[q]);
+    for (int q = lane; q < N.n_uc; q += 64) tab[N.n_ub + q] = exp(-gptr(N.r_uc)[q] / Tgas);
+    wave_sync();
+  }
+  // a reaction's row is fetched while the row before it is being evaluated: the loop is a chain of table loads otherwise (75 trips of ~2 us)
+  struct Row { int it, fsel, a, b; double A, B, C, T0, T1; };
+  auto load_row = [&](int r_) {
+    const int r = min(r_, N.nR - 1);
+    Row q;
+    q.it = gptr(N.r_itype)[r]; q.fsel = gptr(N.r_fss)[r]; q.a = gptr(N.r_re0)[r]; q.b = gptr(N.r_re1)[r];
+    q.A = gptr(N.r_A)[r]; q.B = gptr(N.r_B)[r]; q.C = gptr(N.r_C)[r]; q.T0 = gptr(N.r_T0)[r]; q.T1 = gptr(N.r_T1)[r];
+    return q;
+  };
+  Row nxt = load_row(lane);
   for (int r = lane; r < N.nR; r += 64) {
-    const int it = gptr(N.r_itype)[r];
-    const double A = gptr(N.r_A)[r], B = gptr(N.r_B)[r], C = gptr(N.r_C)[r], T0 = gptr(N.r_T0)[r], T1 = gptr(N.r_T1)[r];
-    const int fsel = gptr(N.r_fss)[r];
+    const Row row = nxt;
+    nxt = load_row(r + 64);
+    const int it = row.it;
+    const double A = row.A, B = row.B, C = row.C, T0 = row.T0, T1 = row.T1;
+    const int fsel = row.fsel;
     const double fI = fsel ? cell[19 + fsel - 1] : 1.0, fS = fsel ? cell[23 + fsel - 1] : 1.0;
-    const int a = gptr(N.r_re0)[r], b = gptr(N.r_re1)[r];
+    const int a = row.a, b = row.b;
     double k = 0.0;
     switch (it) {
       case 5: case 6: {
@@ -149,7 +168,8 @@ RG_DEV void dev_rates(const DevNet &N, const DevParams &P, const double *__restr
         if (it == 5 && C < 0.0) { if (T0 > Tgas) Te = T0; else if (T1 < Tgas) Te = T1; }
         const bool zero = (it == 5) ? (Tgas <= 0.0) : (T0 > Tgas || T1 < Tgas);
         const double base = (Te == Tgas) ? T300 : Te / 300.0;
-        k = zero ? 0.0 : A * pow(base, B) * exp(-C / Te);
+        if (tabbed && Te == Tgas) { const uint32_t ibc = gptr(N.r_ibc)[r]; k = zero ? 0.0 : A * tab[ibc & 0xffffu] * tab[N.n_ub + (ibc >> 16)]; }
+        else k = zero ? 0.0 : A * pow(base, B) * exp(-C / Te);
       } break;
       case 1: k = A * (cr + xr); break;
       case 2: case 20: k = A * (C / (1.0 - cell[8]) * cr + xr); break;

@@ -73,6 +73,27 @@ RG_DEV double hc_lut(const RG_GLOBAL IonLut &L, double x, double y) { // spline2
   return A * v0 + B * v1 + C * 0.0 + D * 0.0;
 }
 static __shared__ volatile double g_hc_terms[HC_NTERMS];
+static __shared__ double g_hc_base[HC_NTERMS]; // dev_T_border: the terms of the unperturbed state
+// the blocks of dev_heating_cooling in the order they are evaluated (bits of its mask)
+enum { HCB_PE = 0, HCB_H2FORM, HCB_CR, HCB_VIBH2, HCB_CI, HCB_PHD_H2, HCB_PHD_H2O, HCB_PHD_OH, HCB_XRAY, HCB_VISC, HCB_CHEM, HCB_C_PE, HCB_C_VIBH2, HCB_C_GG,
+       HCB_C_OI, HCB_C_CII, HCB_C_H2O, HCB_C_CO, HCB_C_H2, HCB_C_LYA, HCB_C_FB, HCB_C_FF, HCB_C_IONS, HCB_C_OH };
+// Which blocks read the abundance of each of chem_ode_jac's ten T-row species (H2, H, E-, C, C+, O, O2, CO, H2O, OH, reference
+// src/disk.f90:4878-4899): the chemical heating reads every abundance; the viscous term reads the charge of the positive ions (C+ here);
+// H2 formation reads X(gH), or X(H) in a network without gH.  tests/test_gpu_evolT.py compares the row these masks give with the row of
+// ten full evaluations, bit for bit.
+#define HCM(b) (1u << (b))
+constexpr unsigned kHcRowMask[10] = {
+    HCM(HCB_CHEM) | HCM(HCB_VIBH2) | HCM(HCB_PHD_H2) | HCM(HCB_XRAY) | HCM(HCB_C_VIBH2) | HCM(HCB_C_GG) | HCM(HCB_C_CII) | HCM(HCB_C_H2O) | HCM(HCB_C_CO) | HCM(HCB_C_H2) | HCM(HCB_C_OH), // H2
+    HCM(HCB_CHEM) | HCM(HCB_XRAY) | HCM(HCB_C_GG) | HCM(HCB_C_OI) | HCM(HCB_C_LYA),                                                                                              // H (+ H2 formation without gH)
+    HCM(HCB_CHEM) | HCM(HCB_PE) | HCM(HCB_XRAY) | HCM(HCB_C_PE) | HCM(HCB_C_OI) | HCM(HCB_C_LYA) | HCM(HCB_C_FB) | HCM(HCB_C_FF) | HCM(HCB_C_IONS),                              // E-
+    HCM(HCB_CHEM) | HCM(HCB_CI),                                                                                                                                                 // C
+    HCM(HCB_CHEM) | HCM(HCB_C_CII) | HCM(HCB_VISC),                                                                                                                              // C+
+    HCM(HCB_CHEM) | HCM(HCB_C_OI),                                                                                                                                               // O
+    HCM(HCB_CHEM),                                                                                                                                                               // O2
+    HCM(HCB_CHEM) | HCM(HCB_C_CO),                                                                                                                                               // CO
+    HCM(HCB_CHEM) | HCM(HCB_PHD_H2O) | HCM(HCB_C_H2O),                                                                                                                           // H2O
+    HCM(HCB_CHEM) | HCM(HCB_PHD_OH) | HCM(HCB_C_OH)};                                                                                                                            // OH
+#undef HCM
 #define HC_BLOCK() asm volatile("" ::: "memory")
 RG_DEV double hc_tau2beta(double tau) { // tau2beta (src/sub_trivials.f90:1064-1085), factor 3
   if (tau <= 1e-4) return 1.0;
@@ -92,7 +113,9 @@ __device__ __attribute__((noinline))
 RG_DEV
 #endif
 double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const double *__restrict__ cell, const double *__restrict__ hr,
-                                  const double *y, double T, const double *__restrict__ rates, double rh2, int lane, double *terms = nullptr) {
+                                  const double *y, double T, const double *__restrict__ rates, double rh2, int lane, double *terms = nullptr, unsigned mask = ~0u) {
+  // mask: bit b set = block b (HCB_*) is evaluated; a block that is not keeps the value g_hc_terms holds (dev_T_border: the terms of the
+  // unperturbed state), and the sum is taken over all of them in the reference's order either way
   using namespace hcc;
   const RG_GLOBAL HcConfig &cfg = H.cfg;
   auto ab = [&](int i) { return i >= 0 ? y[i] : 0.0; };
@@ -145,7 +168,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
   volatile double *r = g_hc_terms;
   // ---- heating -------------------------------------------------------------------------------------------------------------
   HC_BLOCK();
-  { // photoelectric, small grains (Bakes & Tielens 1994 as the reference codes it)
+  if (mask & (1u << HCB_PE)) { // photoelectric, small grains (Bakes & Tielens 1994 as the reference codes it)
     double v = 0.0;
     if (!(X_E <= 0.0 || T <= 0.0)) {
       const double n_e = X_E * n_gas, tmp = chi_all * sqrt(T) / (n_e + very_small);
@@ -156,25 +179,25 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_H_PE] = v;
   }
   HC_BLOCK();
-  r[HC_H_H2FORM] = 2.4e-12 * R_H2_form * cfg.heating_eff_H2form;
+  if (mask & (1u << HCB_H2FORM)) r[HC_H_H2FORM] = 2.4e-12 * R_H2_form * cfg.heating_eff_H2form;
   HC_BLOCK();
-  r[HC_H_CR] = 1.5e-11 * cell[9] * n_gas * exp(-Ncol_ISM / cst::CRattenN);
+  if (mask & (1u << HCB_CR)) r[HC_H_CR] = 1.5e-11 * cell[9] * n_gas * exp(-Ncol_ISM / cst::CRattenN);
   HC_BLOCK();
-  {
+  if (mask & (1u << HCB_VIBH2)) {
     double v = 0.0;
     if (T > 0.0) { const double g10 = 5.4e-13 * sqrt(T); v = (n_gas * X_H2) * chi_H2 * 9.4e-22 / (1.0 + (1.9e-6 + chi_H2 * 4.7e-10) / (n_gas * g10)); }
     r[HC_H_VIBH2] = v;
   }
   HC_BLOCK();
-  r[HC_H_CI] = 2.2e-22 * X_CI * n_gas * chi_all;
+  if (mask & (1u << HCB_CI)) r[HC_H_CI] = 2.2e-22 * X_CI * n_gas * chi_all;
   HC_BLOCK();
-  r[HC_H_PHD_H2] = cfg.use_phdheating_H2 ? 4e-14 * (n_gas * X_H2) * 3.4e-10 * chi_H2 * cfg.heating_eff_phd_H2 : 0.0;
+  if (mask & (1u << HCB_PHD_H2)) r[HC_H_PHD_H2] = cfg.use_phdheating_H2 ? 4e-14 * (n_gas * X_H2) * 3.4e-10 * chi_H2 * cfg.heating_eff_phd_H2 : 0.0;
   HC_BLOCK();
-  r[HC_H_PHD_H2O] = cfg.use_phdheating_H2OOH ? (8.07e-12 * cfg.heating_eff_phd_H2O) * (n_gas * X_H2O) * LyA_H2O * (cell[18] * cell[25]) : 0.0;
+  if (mask & (1u << HCB_PHD_H2O)) r[HC_H_PHD_H2O] = cfg.use_phdheating_H2OOH ? (8.07e-12 * cfg.heating_eff_phd_H2O) * (n_gas * X_H2O) * LyA_H2O * (cell[18] * cell[25]) : 0.0;
   HC_BLOCK();
-  r[HC_H_PHD_OH] = cfg.use_phdheating_H2OOH ? (9.19e-12 * cfg.heating_eff_phd_OH) * (n_gas * X_OH) * LyA_OH * (cell[18] * cell[26]) : 0.0;
+  if (mask & (1u << HCB_PHD_OH)) r[HC_H_PHD_OH] = cfg.use_phdheating_H2OOH ? (9.19e-12 * cfg.heating_eff_phd_OH) * (n_gas * X_OH) * LyA_OH * (cell[18] * cell[26]) : 0.0;
   HC_BLOCK();
-  { // X-ray heating per ion pair (Glassgold et al. 2012)
+  if (mask & (1u << HCB_XRAY)) { // X-ray heating per ion pair (Glassgold et al. 2012)
     double v = 0.0;
     if (cfg.use_Xray_heating) {
       double gam1 = 0.0, gam2 = 0.0;
@@ -199,7 +222,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_H_XRAY] = v;
   }
   HC_BLOCK();
-  {
+  if (mask & (1u << HCB_VISC)) {
     double v = 0.0;
     if (T > 0.0) {
       const double mmw = hr[H_MMW], rho = n_gas * cst::mP * mmw, c2 = cst::kB * T / (cst::mP * mmw), fcut = fmax(1.0 - T / 2e4, 0.0);
@@ -208,7 +231,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_H_VISC] = v;
   }
   HC_BLOCK();
-  { // chemical heating: sum over the reactions with a heat, k * y_a * y_b * heat
+  if (mask & (1u << HCB_CHEM)) { // chemical heating: sum over the reactions with a heat, k * y_a * y_b * heat
     double v = 0.0;
     if (cfg.use_chemicalheatingcooling && T > 0.0) {
       double s = 0.0;
@@ -222,7 +245,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
   }
   // ---- cooling -------------------------------------------------------------------------------------------------------------
   HC_BLOCK();
-  {
+  if (mask & (1u << HCB_C_PE)) {
     double v = 0.0;
     if (!(X_E <= 0.0 || T <= 0.0 || PAH <= 0.0)) {
       const double n_e = X_E * n_gas, tmp = chi_all * sqrt(T) / (n_e + very_small);
@@ -234,7 +257,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_C_PE] = v;
   }
   HC_BLOCK();
-  {
+  if (mask & (1u << HCB_C_VIBH2)) {
     double v = 0.0;
     if (T > 0.0) {
       const double g10 = 5.4e-13 * sqrt(T), A10 = 8.6e-7, D1 = 2.6e-11;
@@ -243,7 +266,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_C_VIBH2] = v;
   }
   HC_BLOCK();
-  { // gas-grain collisions
+  if (mask & (1u << HCB_C_GG)) { // gas-grain collisions
     double v = 0.0;
     if (T > 0.0) {
       if (!cfg.use_mygasgraincooling) {
@@ -265,7 +288,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
   }
 #define Ncool fmin(fmin(Ncol_ISM, Ncol_star), n_gas * coh)
   HC_BLOCK();
-  { // [OI] 63, 146 um and 6300 A, analytic
+  if (mask & (1u << HCB_C_OI)) { // [OI] 63, 146 um and 6300 A, analytic
     double v = 0.0;
     if (T > 0.0) {
       const double Z = X_OI / 3.2e-4;
@@ -283,7 +306,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_C_OI] = v;
   }
   HC_BLOCK();
-  {
+  if (mask & (1u << HCB_C_CII)) {
     double v = 0.0;
     if (T > 0.0) {
       const double Z = X_CII / 1.4e-4, beta = hc_tau2beta(Ncool * Z / 6.5e20);
@@ -294,7 +317,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
 #define n_H2 (n_gas * X_H2)
   const double ln10 = log(10.0);
   HC_BLOCK();
-  { // Neufeld H2O, rotational and vibrational
+  if (mask & (1u << HCB_C_H2O)) { // Neufeld H2O, rotational and vibrational
     double vr = 0.0, vv = 0.0;
     if (!(X_H2O <= 0.0 || X_H2 <= 0.0 || T <= 0.0)) {
       const RG_GLOBAL NeufeldH2O &W = H.h2o;
@@ -340,7 +363,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_C_H2O_ROT] = vr; r[HC_C_H2O_VIB] = vv;
   }
   HC_BLOCK();
-  { // Neufeld CO
+  if (mask & (1u << HCB_C_CO)) { // Neufeld CO
     double vr = 0.0, vv = 0.0;
     if (!(X_CO <= 0.0 || X_H2 <= 0.0 || T <= 0.0)) {
       const RG_GLOBAL NeufeldCO &W = H.co;
@@ -377,7 +400,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_C_CO_ROT] = vr; r[HC_C_CO_VIB] = vv;
   }
   HC_BLOCK();
-  { // Neufeld H2 rotational
+  if (mask & (1u << HCB_C_H2)) { // Neufeld H2 rotational
     double v = 0.0;
     if (!(T <= 0.0 || X_H2 <= 0.0)) {
       const RG_GLOBAL NeufeldH2 &W = H.h2;
@@ -394,9 +417,9 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_C_H2_ROT] = v;
   }
   HC_BLOCK();
-  r[HC_C_LYA] = T > 0.0 ? 7.3e-19 * (n_gas * n_gas) * X_HI * X_E * exp(-118400.0 / T) : 0.0;
+  if (mask & (1u << HCB_C_LYA)) r[HC_C_LYA] = T > 0.0 ? 7.3e-19 * (n_gas * n_gas) * X_HI * X_E * exp(-118400.0 / T) : 0.0;
   HC_BLOCK();
-  {
+  if (mask & (1u << HCB_C_FB)) {
     double v = 0.0;
     if (T > 0.0) {
       const double n_p = n_gas * X_Hplus, n_E = n_gas * X_E, t1 = log(T / 1e4 / 1.0), t2 = exp(t1 * (-0.7131 - 0.0115 * t1));
@@ -405,9 +428,9 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_C_FB] = v;
   }
   HC_BLOCK();
-  r[HC_C_FF] = T > 0.0 ? 1.4e-27 * 1.0 * sqrt(T) * 1.3 * (n_gas * X_E) * (n_gas * (X_Hplus + X_Heplus)) : 0.0;
+  if (mask & (1u << HCB_C_FF)) r[HC_C_FF] = T > 0.0 ? 1.4e-27 * 1.0 * sqrt(T) * 1.3 * (n_gas * X_E) * (n_gas * (X_Hplus + X_Heplus)) : 0.0;
   HC_BLOCK();
-  {
+  if (mask & (1u << HCB_C_IONS)) {
     auto ion = [&](double X, const RG_GLOBAL IonLut &L) {
       if (X <= 1e-15 || X_E <= 0.0 || n_gas <= 0.0 || T <= 0.0) return 0.0;
       return X * n_gas * exp(ln10 * hc_lut(L, log10(X_E * n_gas), log10(T)));
@@ -415,7 +438,7 @@ double dev_heating_cooling(const DevNet &N, const RG_GLOBAL DevHC &H, const doub
     r[HC_C_NII] = ion(X_NII, H.nii); r[HC_C_SIII] = ion(X_SiII, H.siii); r[HC_C_FEII] = ion(X_FeII, H.feii);
   }
   HC_BLOCK();
-  { // OH rotational (Hollenbach & McKee 1989; Gorti & Hollenbach 2004)
+  if (mask & (1u << HCB_C_OH)) { // OH rotational (Hollenbach & McKee 1989; Gorti & Hollenbach 2004)
     double v = 0.0;
     if (!(X_OH <= 0.0 || X_H2 < 0.0 || X_H2 >= 1.0 || T <= 0.0)) {
       const double A0 = 7.6e-4, E0 = 5.4, sig = 8e-16, eta = 10.0;

@@ -185,6 +185,8 @@ RG_DEV void dev_pascal(const CellCtx &c, const Lsodes &s, bool forward, bool to_
   }
 }
 
+static __shared__ double g_rate_tab[kRateTab]; // dev_rates' table of pow / exp values (k_solve_T and its test hook only)
+
 // f(y) into savf.  ET and the cell's T still evolving: chem_ode_f's three steps (reference src/disk.f90:4569-4659) -- rate
 // coefficients at the iterate's T, the species part, dT/dt.  The rate vector and R_H2_form_rate_coeff stay as this call leaves them.
 template <bool ET>
@@ -192,7 +194,7 @@ RG_DEV void dev_f(const DevNet &N, const CellCtx &c, double *ydot, double *ydotT
   if constexpr (ET) {
     if (g_T.evolT) {
       double T = Tat ? *Tat : g_T.y;
-      dev_rates(N, *c.prm, c.cell, c.rates, c.lane, (double *)&g_T.rh2, &T);
+      dev_rates(N, *c.prm, c.cell, c.rates, c.lane, (double *)&g_T.rh2, &T, g_rate_tab);
       dev_rhs(N, c.rates, g_wc.nsite, gptr(N.r_C), c.y, ydot, c.lane);
       const double td = dev_heating_cooling(N, *(const RG_GLOBAL DevHC *)c.hc, c.cell, c.hcrec, c.y, T, c.rates, g_T.rh2, c.lane);
       if (ydotT) *ydotT = td; else g_T.savf = td;
@@ -207,9 +209,14 @@ RG_DEV void dev_f(const DevNet &N, const CellCtx &c, double *ydot, double *ydotT
 // scaled into the border of P = I + con J.  T row: d(dT/dt)/dy_j for the ten special species with y_j >= 0, step 1e-2 y_j + 1e-6 D2H; the
 // base value is the dT/dt of the f(y) that preceded this call (same y, same rates: g_T.savf).  T column: (f(y, T + dT) - f(y, T)) / dT with
 // dT = 1e-2 T + 1, f(y, T) being savf; the rate vector is left at T + dT, as in the reference.  wx (LDS) is used as scratch.
-RG_DEV void dev_T_border(const DevNet &N, const CellCtx &c, double con) {
+// full_rows (test hook): every row entry by a full evaluation of the 28 terms; otherwise only the blocks that read the moved abundance are
+// evaluated again (kHcRowMask), the others keep the value of the unperturbed state, which g_hc_terms holds from the f(y) before this call.
+RG_DEV void dev_T_border(const DevNet &N, const CellCtx &c, double con, bool full_rows = false) {
   const RG_GLOBAL DevHC &H = *(const RG_GLOBAL DevHC *)c.hc;
   const double Tc = g_T.y, r1 = g_T.savf, d2h = c.cell[6];
+  wave_sync();
+  if (c.lane < HC_NTERMS) g_hc_base[c.lane] = g_hc_terms[c.lane];
+  wave_sync();
   for (int k = 0; k < 10; ++k) {
     const int j = H.idx10[k];
     double pc = 0.0;
@@ -220,7 +227,12 @@ RG_DEV void dev_T_border(const DevNet &N, const CellCtx &c, double con) {
         wave_sync();
         if (c.lane == 0) c.y[j] = yj + dy;
         wave_sync();
-        const double r2 = dev_heating_cooling(N, H, c.cell, c.hcrec, c.y, Tc, c.rates, g_T.rh2, c.lane);
+        unsigned mask = kHcRowMask[k];
+        if (k == 1 && H.i_gH < 0) mask |= 1u << HCB_H2FORM;
+        if (full_rows) mask = ~0u;
+        if (c.lane < HC_NTERMS) g_hc_terms[c.lane] = g_hc_base[c.lane];
+        wave_sync();
+        const double r2 = dev_heating_cooling(N, H, c.cell, c.hcrec, c.y, Tc, c.rates, g_T.rh2, c.lane, nullptr, mask);
         wave_sync();
         if (c.lane == 0) c.y[j] = yj;
         wave_sync();

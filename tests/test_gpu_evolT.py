@@ -89,6 +89,30 @@ def test_jacobian_T_row_and_column_match_reference(racgpu, ev):
         assert bad.size == 0, (int(g["grid_idx"][c]), bad[:5], out["tcol"][c][bad[:5]], ref[bad[:5]])
 
 
+def test_T_row_by_blocks_is_the_T_row_by_full_evaluations(racgpu, ev):
+    """The production path re-evaluates, for each of the ten T-row species, only the blocks of the heating/cooling function that read its
+    abundance (kHcRowMask, engine_hc.hpp).  Against ten FULL evaluations (developer switch): the same bits, at the start state, at the end
+    state and at randomly disturbed states of the eight fixture cells -- a block missing from a mask would change its row entry."""
+    g, net = ev
+    nS = net.nSpecies
+    p = racgpu.default_params()
+    rng = np.random.default_rng(7)
+    y0 = np.hstack([net.init_abundances(g["y0"], g["cells"]), g["cells"][:, :1]])
+    yend = g["yend"][:, :nS + 1].copy()
+    states = [y0, yend]
+    for _ in range(3):
+        yy = yend.copy()
+        yy[:, :nS] *= 10.0 ** rng.uniform(-1.0, 1.0, (len(yy), nS))     # every abundance moved by up to a factor of ten
+        yy[:, nS] *= rng.uniform(0.5, 2.0, len(yy))
+        states.append(yy)
+    for y in states:
+        a = net.ode_f_evolT(p, g["cells"], g["hc"], y, jac_border=True)
+        b = net.ode_f_evolT(p, g["cells"], g["hc"], y, jac_border=True, full_rows=True)
+        np.testing.assert_array_equal(a["trow"], b["trow"])
+        np.testing.assert_array_equal(a["tcol"], b["tcol"])
+        assert np.isfinite(a["trow"]).all() and (a["trow"] != 0).any()
+
+
 def test_heat_reactions_are_the_references(racgpu, ev):
     g, net = ev
     rx, ht = net.heat_reactions()
