@@ -185,7 +185,7 @@ static __shared__ double g_rec[RACGPU_NPAR + kNHC]; // k_solve_T: the cell recor
 
 template <int TEAM, bool RESUME, bool COLUMN = false, bool ET = false>
 RG_DEV void solve_body(const DevNet &N, const DevParams &P, const DevWork &W, const SolveArgs &A, double *lds) {
-  static_assert(!ET || (TEAM == 1 && !RESUME && !COLUMN), "the evolT kernel is one wave per cell");
+  static_assert(!ET || (!RESUME && !COLUMN), "evolT: one wave per cell, or a team from the start; no hand-over, no columns");
   const int lane = threadIdx.x & 63, wv = TEAM > 1 ? uniform_i((int)(threadIdx.x >> 6)) : 0;
   const int n = N.nS, nlds = (n + 1) & ~1;
   LdsViews v = carve(lds, nlds);
@@ -440,6 +440,11 @@ __global__ __launch_bounds__(64 * kTeam) void k_solve_team(const DevNet *__restr
 __global__ __launch_bounds__(64) void k_solve_T(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
   extern __shared__ double lds[];
   solve_body<1, false, false, true>(*Np, *Pp, W, A, lds);
+}
+// the same for the cells the cost hints single out: four waves (factorisation and Jacobian shared out; f, the 28 terms and the border stay on wave 0)
+__global__ __launch_bounds__(64 * kTeam) void k_solve_team_T(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
+  extern __shared__ double lds[];
+  solve_body<kTeam, false, false, true>(*Np, *Pp, W, A, lds);
 }
 // columns of cells in dependency order, one team per column at a time (racgpu_column_sweep)
 __global__ __launch_bounds__(64 * kTeam) void k_solve_columns(const DevNet *__restrict__ Np, const DevParams *__restrict__ Pp, DevWork W, SolveArgs A) {
@@ -1424,11 +1429,36 @@ static void solve_pass(racgpu_network *h, const DevParams &P, long ncell, const 
     if (const char *e = std::getenv("RACGPU_PARK_PER_CU")) park_per_cu = std::max(1, std::atoi(e)); // developer aid
     const int park_max = h->park_enabled ? h->cu_count * park_per_cu : 0;
     A.park_max = park_max; A.park_list = h->ws.counter + 16; A.park_count = h->ws.counter + 4;
-    if (B.hc) { // gas temperature co-evolving: one wave per cell throughout (no teams, no hand-over)
+    if (B.hc) { // gas temperature co-evolving: one wave per cell, four for the cells the cost hints single out; no hand-over
       A.hc = B.hc + (size_t)c0 * kNHC; A.hc_tab = h->hc_dev; A.park_max = 0;
-      const long grid = std::max<long>(1, std::min<long>(slots, A.ncell));
-      hipLaunchKernelGGL(k_solve_T, dim3((unsigned)grid), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, A);
-      HIP_OK(hipGetLastError());
+      long nteamc = 0;
+      if (team_cap > 0) {
+        const double *cost = h->cost_hints.data() + c0;
+        double total = 0.0;
+        for (long i = 0; i < nc; ++i) total += cost[i];
+        const double thr = h->team_frac * total / (double)slots;
+        while (nteamc < std::min<long>(team_cap, nc) && cost[h->order_host[c0 + nteamc]] > thr) ++nteamc;
+      }
+      if (nteamc > 0) {
+        SolveArgs T = A;
+        T.ncell = (int)nteamc; T.slot0 = (int)slots;
+        DevWork Wt = h->ws;
+        Wt.counter = h->ws.counter + 2;
+        HIP_OK(hipEventRecord(h->ev_fork, h->stream));
+        HIP_OK(hipStreamWaitEvent(h->team_stream, h->ev_fork, 0));
+        hipLaunchKernelGGL(k_solve_team_T, dim3((unsigned)nteamc), dim3(64 * kTeam), lds_bytes_team(h->dn), h->team_stream, h->dn_dev, h->dp_dev, Wt, T);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(h->ev_join, h->team_stream));
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, h->stream, (const int *)(h->ws.counter + 1), (int)nteamc, 48000000LL);
+        A.ncell = (int)(nc - nteamc); A.order += nteamc;
+        h->last_team_cells += nteamc;
+      }
+      if (A.ncell > 0) {
+        const long grid = std::max<long>(1, std::min<long>(slots, A.ncell));
+        hipLaunchKernelGGL(k_solve_T, dim3((unsigned)grid), dim3(64), lds, h->stream, h->dn_dev, h->dp_dev, h->ws, A);
+        HIP_OK(hipGetLastError());
+      }
+      if (nteamc > 0) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
       continue;
     }
     // Cells that would take more than team_frac of the pass's ideal length on their own (sum of costs / wave slots) go to

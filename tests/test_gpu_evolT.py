@@ -172,3 +172,25 @@ def test_cells_without_energy_gain_keep_their_temperature(racgpu, ev):
     b = net.evol_solve_batch(p, g["cells"][:3], y0[:3])
     assert np.array_equal(a["y"], b["y"]) and np.array_equal(a["t_final"], b["t_final"])
     assert (a["cell_out"][:, racgpu.O_TGAS] == g["cells"][:3, 0]).all()
+
+
+def test_four_waves_on_an_evolT_cell_give_the_bits_of_one(racgpu, ev):
+    """With cost hints the costliest cells of an evolT batch start on a team of four waves (k_solve_team_T: the factorisation and the
+    Jacobian shared out, f(y), the 28 terms and the border on wave 0).  Abundances, temperatures, times, counters: the bits of the
+    one-wave run."""
+    g, net = ev
+    p = racgpu.default_params()
+    y0 = net.init_abundances(g["y0"], g["cells"])
+    net.set_cost_hints(None)
+    a = net.evolT_solve_batch(p, g["cells"], g["hc"], y0)
+    assert net.last_team_cells() == 0
+    cost = np.ones(len(g["cells"])); cost[[1, 4, 6]] = 1e6          # three cells far above the team threshold
+    net.set_cost_hints(cost)
+    b = net.evolT_solve_batch(p, g["cells"], g["hc"], y0)
+    net.set_cost_hints(None)
+    assert net.last_team_cells() == 3
+    for k in ("y", "t_final", "quality", "cell_out"):
+        np.testing.assert_array_equal(a[k], b[k])
+    S = racgpu
+    for col in (S.S_NST, S.S_NFE, S.S_NJE, S.S_NLU, S.S_NERR, S.S_QSUM, S.S_ERRCODES):
+        np.testing.assert_array_equal(a["stats"][:, col], b["stats"][:, col])
