@@ -550,7 +550,7 @@ def main():
                          "traffic_frac_of_peak": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          # one pass = k_solve (one wave per cell) followed by k_solve_team_resume (the cells handed over at its end),
                          # with k_solve_team (cells in teams from the start) alongside: timed as a whole between two HIP events
-                         "kernel": "k_solve_T" if args.evolT else "k_solve_columns" if colgrid is not None else "k_solve (+ k_solve_team, k_solve_team_resume)", "kernel_ms": kms,
+                         "kernel": "k_solve_T (+ k_solve_team_T)" if args.evolT else "k_solve_columns" if colgrid is not None else "k_solve (+ k_solve_team, k_solve_team_resume)", "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_cell_step": abytes / max(nst, 1.0)},
             "cell_steps_per_pass_rank0": nst, "mean_steps_per_cell": nst / ncell,

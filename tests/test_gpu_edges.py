@@ -1,6 +1,7 @@
 """Edge cases of the batch interface on the GPU: empty and ragged batches, per-cell t_max, the deterministic work
 budgets, the not-implemented switches, device-resident buffers, determinism."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -184,3 +185,26 @@ def test_rate12_tight_tolerance_config(racgpu):
     out = net.evol_solve_batch(p, g["cells"], net.init_abundances(g["y0"], g["cells"]))
     for c in range(len(g["cells"])):
         assert major_relerr(out["y"][c], g["yend"][c][:net.nSpecies]) <= 1e-5
+
+
+def test_multi_gpu_entry_point_with_one_device_is_the_single_device_call(racgpu, setup):
+    """racgpu_multi_calc_cells (one process, a host thread per device, RCCL all-gather of the packed result rows) with ndev = 1: dealing,
+    packing and merging on, the collective skipped.  The results are those of racgpu_calc_cells on the same cells, bit for bit, with and
+    without cost hints (which change the dealing, not the results)."""
+    net, y0 = setup
+    cells = np.stack([racgpu.cells.make_cell(50.0, 40.0, 1e8, 5.0, 1e3), racgpu.cells.make_cell(300.0, 300.0, 1e10, 5.0, 1e3),
+                      racgpu.cells.make_cell(20.0, 15.0, 1e6, 2.0, 1e2), racgpu.cells.make_cell(800.0, 400.0, 1e9, 1.0, 1e4),
+                      racgpu.cells.make_cell(100.0, 80.0, 1e7, 3.0, 1e3)])
+    p = racgpu.default_params(); p.t_max = 1e3
+    y = net.init_abundances(y0, cells)
+    one = net.calc_cells(p, cells, y, nlocal_iter=2)
+    m = racgpu.MultiGPU(os.path.join(DATA, "rate06_dipole_reformated_again_withoutgrain.dat"), 1)
+    try:
+        assert m.ndev == 1
+        for cost in (None, np.array([3.0, 1.0, 5.0, 2.0, 4.0])):
+            multi = m.calc_cells(p, cells, y, nlocal_iter=2, cost=cost)
+            for k in ("y", "t_final", "quality"):
+                np.testing.assert_array_equal(multi[k], one[k])
+            np.testing.assert_array_equal(multi["stats"][:, :8], one["stats"][:, :8])
+    finally:
+        m.close()
