@@ -105,6 +105,7 @@ struct DevNet {
   // type-11 special indices (0-based, -1 none)
   int i_H, i_E, i_gH, i_gH2, i_gH2O, i_Grain0, i_GrainM, i_GrainP;
   int i_H2;                  // hand-off test (reference src/disk.f90:1716-1721)
+  int charge_conserved;      // 1: RACGPU_CHARGE_BALANCE is set, every reaction conserves charge and E- is a species (dev_rhs; off by default)
   int grain_conserved;       // 1: every reaction has as many Grain0/Grain-/Grain+ among its reactants as among its products (dev_rhs)
   int moeq_r61, moeq_r62;    // H2_form_use_moeq: the adsorption reaction of H and the desorption reaction of gH (-1 none)
   int r_h2form;              // last reaction whose coefficient the reference copies into R_H2_form_rate_coeff (-1 none)

@@ -919,6 +919,19 @@ void racgpu_network::upload() {
       if (a != b && h.kind((int)(&x - &h.R[0])) != K_NONE) dn.grain_conserved = 0;
     }
   }
+  {
+    // charge conservation (dev_rhs): E- must be a species with charge -1 and every reaction chem_ode_f acts on must balance
+    dn.charge_conserved = (h.idx10[2] > 0 && h.elements[h.idx10[2] - 1][0] == -1) ? 1 : 0;
+    for (int r = 0; r < nR && dn.charge_conserved; ++r) {
+      const Reaction &x = h.R[r];
+      if (h.kind(r) == K_NONE) continue;
+      int q = 0;
+      for (int k = 0; k < x.n_reac; ++k) q += h.elements[x.reac[k] - 1][0];
+      for (int k = 0; k < x.n_prod; ++k) q -= h.elements[x.prod[k] - 1][0];
+      if (q != 0) dn.charge_conserved = 0;
+    }
+    if (!std::getenv("RACGPU_CHARGE_BALANCE")) dn.charge_conserved = 0; // developer switch, off by default (dev_rhs says why)
+  }
   dn.r_h2form = -1; // chem_cal_rates stores the coefficient of every itype-0 and every gH-first itype-63 reaction in turn: the last one stays
   for (int r = 0; r < nR; ++r)
     if (h.R[r].itype == 0 || (h.R[r].itype == 63 && h.R[r].rname[0] == "gH")) dn.r_h2form = r;
