@@ -356,33 +356,6 @@ RG_DEV void dev_rhs(const DevNet &N, const double *__restrict__ rates, double ns
     if (lane == 0) ydot[N.i_Grain0] = -((N.i_GrainM >= 0 ? ydot[N.i_GrainM] : 0.0) + (N.i_GrainP >= 0 ? ydot[N.i_GrainP] : 0.0));
     wave_sync();
   }
-  for (int sweep = 0; sweep < RG_EXP_ELEM_SWEEPS; ++sweep)
-#ifndef RG_EXP_ELEM_MASK
-#define RG_EXP_ELEM_MASK 0xfffff
-#endif
-  for (int e = 3; e < 20; ++e) {
-    if (!((RG_EXP_ELEM_MASK >> e) & 1)) continue;
-    double r = 0.0, best = -1.0; int bi = -1;
-    for (int i = lane; i < N.nS; i += 64) {
-      const int ne = gptr(N.s_elem)[(size_t)e * N.nS + i];
-      if (ne != 0) {
-        const double t = (double)ne * ydot[i];
-        r += t;
-        if ((RG_EXP_ELEM == 2 || gptr(N.s_pure)[i] == 1 + e) && fabs(t) > best) { best = fabs(t); bi = i; }
-      }
-    }
-    r = wave_sum(r);
-    double bm = best;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) bm = fmax(bm, __shfl_xor(bm, m, 64));
-    const unsigned long long who = __ballot(best == bm && bi >= 0);
-    if (who != 0ULL && bm > 0.0) {
-      const int src = __builtin_ctzll(who);
-      if (lane == src) ydot[bi] = ydot[bi] - r / (double)gptr(N.s_elem)[(size_t)e * N.nS + bi];
-    }
-    wave_sync();
-  }
-#endif
   // Charge (OFF by default: racgpu developer switch RACGPU_CHARGE_BALANCE=1).  Every reaction conserves it, so in exact arithmetic
   // sum_i q_i f_i = 0 and the electron's rate could be taken from the balance of all the others, as the grain balance above.  Measured
   // (profiles/r3_tuning.txt, item 5): it lets the hot configs[1] cells that used to stall finish like the reference's -- and makes other
