@@ -40,9 +40,35 @@ static int flux(const orc_network *net, const orc_params *p, const double *cell,
   *out = rtmp; return 1;
 }
 
+/* Developer experiment (ORC_F_ORDER=scatter in the environment): the sums of chem_ode_f in the ORDER the GPU engine's LDS scatter adds them
+ * -- 64 reactions per pass; within a pass target slot by target slot (reactants first, then products), the reactions of the pass in
+ * order within a slot -- instead of the reference's reaction-by-reaction order.  Same terms, other rounding: tools/dev/oracle_f_order.py uses
+ * it to ask whether that order is what makes hot cells stall on the GPU. */
+static int f_order_scatter(void) {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("ORC_F_ORDER"); v = (e && strcmp(e, "scatter") == 0) ? 1 : 0; }
+  return v;
+}
+
 void orc_ode_f(const orc_network *net, const orc_params *p, const double *cell, const double *rates,
                const double *y, double *ydot) {
   for (int i = 0; i < net->NEQ; i++) ydot[i] = 0.0;
+  if (f_order_scatter()) {
+    for (int p0 = 0; p0 < net->nR; p0 += 64) {
+      double fl[64]; int ok[64];
+      const int m = net->nR - p0 < 64 ? net->nR - p0 : 64;
+      for (int l = 0; l < m; l++) ok[l] = flux(net, p, cell, rates, y, p0 + l, &fl[l], NULL);
+      for (int s = 0; s < 7; s++)
+        for (int l = 0; l < m; l++) {
+          const int i = p0 + l;
+          if (!ok[l]) continue;
+          if (s < net->n_reac[i]) ydot[net->reac[3 * i + s] - 1] -= fl[l];
+          else if (s - net->n_reac[i] < net->n_prod[i]) ydot[net->prod[4 * i + (s - net->n_reac[i])] - 1] += fl[l];
+        }
+    }
+    ydot[net->nS] = 0.0;
+    return;
+  }
   for (int i = 0; i < net->nR; i++) {
     double rtmp;
     if (!flux(net, p, cell, rates, y, i, &rtmp, ydot)) continue;
