@@ -152,6 +152,64 @@ def write_contributions(f, net, t, y, rates, cell, species, tables=None):
                     break
 
 
+def analysed_records(touts, record, n_record_real, incr=0, frac=0.1):
+    """The records chem_analyse visits (reference src/disk.f90:4176-4208): every incr-th of the first n_record_real (incr <= 0: 1 +
+    n_record_real / 20), skipping a record whose largest relative change of y (and T) against the record BEFORE it is below frac times the
+    relative step of t.  1-based record numbers."""
+    touts = np.asarray(touts, dtype=np.float64); record = np.asarray(record, dtype=np.float64)
+    if incr <= 0:
+        incr = 1 + n_record_real // 20
+    out = []
+    for k in range(1, n_record_real + 1, incr):
+        if k >= 2:
+            a, b = record[k - 1], record[k - 2]
+            dy_y = float(np.max(np.abs(a - b) / (a + b + 1e-15)))
+            dt_t = (touts[k - 1] - touts[k - 2]) / (touts[k - 1] + touts[k - 2])
+            if dy_y < frac * dt_t:
+                continue
+        out.append(k)
+    return out
+
+
+def chem_analyse(net, out_dir, cell_id, cell, touts, record, n_record_real, rates_of, species=(), iteration=1, geometry=(0.0, 0.0, 0.0, 0.0),
+                 incr=0, tables=None):
+    """chem_analyse (reference src/disk.f90:4136-4300) on a cell's time record as the engine returns it (Network.evol_solve_batch /
+    evolT_solve_batch with record=True): the three files of a_disk_ana_params%analyse_out_dir,
+      evol_<id>_rz_<xmin>_<ymin>_iter_<it>.dat    '!Time_(yr)', names, 'Tgas' in A14; one ES14.4E4 row (t, y, T) per record
+      ele_...dat, contri_...dat                   a header line with the cell's conditions, then per visited record (analysed_records)
+                                                  the elemental-residence block / the production-destruction ranking of `species`
+    rates_of(Tgas) -> rate coefficients at that temperature (e.g. lambda T: net.cal_rates(params, cell_at(T))[0]): the reference
+    re-evaluates nothing there with T fixed, and with T evolving the record's last column is the temperature of the snapshot.
+    The ranking of reactions by chemical heat at the end of each contri block needs the heating/cooling module's per-reaction heats and is
+    written by the reference only; everything else follows it line by line.  Returns the three paths and the visited records."""
+    import os
+    cell = np.asarray(cell, dtype=np.float64); touts = np.asarray(touts, dtype=np.float64); record = np.asarray(record, dtype=np.float64)
+    nS = net.nSpecies
+    xmin, xmax, ymin, ymax = geometry
+    pre = "%04d_rz_%s_%s_iter_%03d" % (cell_id, ("%.6f" % xmin).lstrip("0") or "0", ("%.6f" % ymin).lstrip("0") or "0", iteration)  # (F0.6)
+    paths = [os.path.join(out_dir, "%s_%s.dat" % (k, pre)) for k in ("evol", "ele", "contri")]
+    with open(paths[0], "w") as f:
+        f.write("!Time_(yr)    " + "".join("  " + ("%-12s" % nm)[:12] for nm in net.names) + "  Tgas        \n")  # (A14 of character(12) names: two blanks, then the name)
+        for k in range(n_record_real):
+            f.write(_es(touts[k], 14, 4, 4) + "".join(_es(v, 14, 4, 4) for v in record[k, :nS + 1]) + "\n")
+    from . import cells as Cc
+    head = "%10.1f%10.1f%s%s%s%5d%5d%s%s%s%s\n" % (cell[Cc.P_TGAS], cell[Cc.P_TDUST], _es(cell[Cc.P_NGAS], 12, 2), _es(cell[Cc.P_AV_STAR], 12, 2),
+                                                   _es(cell[Cc.P_AV_ISM], 12, 2), cell_id, iteration, _es(xmin, 16, 6), _es(xmax, 16, 6), _es(ymin, 16, 6), _es(ymax, 16, 6))
+    visited = analysed_records(touts, record[:, :nS + 1], n_record_real, incr)
+    with open(paths[1], "w") as f1, open(paths[2], "w") as f2:
+        f1.write(head); f2.write(head)
+        for k in visited:
+            y = record[k - 1, :nS]; T = record[k - 1, nS]
+            write_elements(f1, net, touts[k - 1], y, T)
+            if len(species) == 0:
+                f2.write("Time = %s\n" % _es(touts[k - 1], 14, 4))
+                continue
+            c = cell.copy(); c[Cc.P_TGAS] = T
+            write_contributions(f2, net, touts[k - 1], y, rates_of(T), c, list(species), tables)
+            f2.write("Tgas = %s\n" % _es(T, 14, 4))
+    return paths, visited
+
+
 # ---------------------------------------------------------------------------------------------------------
 # iter_NNNN.dat: the per-cell ASCII table of a global iteration (reference write_header / disk_save_results_write,
 # src/disk.f90:2745-2902, 2905-3073).  Row = 2I5, 4I14, 142 ES14.5E3, nSpecies ES14.5E3; header = '!' + the column names right-aligned

@@ -102,3 +102,43 @@ def test_iter_dat_writer_reproduces_the_references_file(racgpu):
     assert mine[0].rstrip() == ref[0].rstrip()
     assert mine[1] == ref[1]
     assert len(d) == 148 + net.nSpecies and d["w_Kep"][0] == pytest.approx(142.142) and d["gH2O"][0] == pytest.approx((net.names.index("gH2O") + 1) * 1e-3)
+
+
+def test_chem_analyse_driver_on_a_time_record(racgpu, tmp_path):
+    """analysis.chem_analyse = the reference's chem_analyse loop (src/disk.f90:4136-4300) over a cell's record: which records it visits
+    (every incr-th, skipping those that moved less than a tenth of the relative time step), the evol_ file (header, one ES14.4E4 row per
+    record), one elemental block per visited record, one ranking block per visited record and species.  Host side only: a synthetic record
+    around the reference's end state of the fixture cell, its own rate coefficients."""
+    A = racgpu.analysis
+    net = _net(racgpu)
+    nS = net.nSpecies
+    yend = G["ana_yend"]
+    nrec = 60
+    touts = 1e-3 * 1.3 ** np.arange(nrec)
+    rec = np.tile(np.r_[yend[:nS], 50.0], (nrec, 1))
+    rec[:40, :nS] *= (1.0 + 2.0 * np.exp(-np.arange(40) / 12.0))[:, None]       # moving at first, then flat: the flat part is skipped
+    visited = A.analysed_records(touts, rec, nrec)
+    want = []
+    for k in range(1, nrec + 1, 1 + nrec // 20):                                # (the reference's loop, src/disk.f90:4196-4208)
+        if k >= 2:
+            dy = np.max(np.abs(rec[k - 1] - rec[k - 2]) / (rec[k - 1] + rec[k - 2] + 1e-15))
+            if dy < 0.1 * (touts[k - 1] - touts[k - 2]) / (touts[k - 1] + touts[k - 2]):
+                continue
+        want.append(k)
+    assert visited == want and visited[0] == 1 and 3 <= len(visited) < len(range(1, nrec + 1, 1 + nrec // 20))
+    assert A.analysed_records(touts, rec, nrec, incr=1)[:3] == [1, 2, 3]
+    cell = G["policy_cells"][0]
+    sp = [net.species_index("CO"), net.species_index("H2O")]
+    paths, vis = A.chem_analyse(net, str(tmp_path), 7, cell, touts, rec, nrec, lambda T: G["ana_rates"], species=sp, geometry=(1.5, 2.0, 0.25, 0.5))
+    assert vis == visited and os.path.basename(paths[0]) == "evol_0007_rz_1.500000_.250000_iter_001.dat"
+    ev = open(paths[0]).read().splitlines()
+    assert len(ev) == nrec + 1 and ev[0].startswith("!Time_(yr)    ") and ev[0].endswith("  Tgas        ") and len(ev[0]) == 14 * (nS + 2)
+    row = np.array([float(ev[5][14 * k:14 * (k + 1)]) for k in range(nS + 2)])
+    np.testing.assert_allclose(row, np.r_[touts[4], rec[4]], rtol=1e-4)
+    el = open(paths[1]).read()
+    assert el.count("Time = ") == len(visited) and el.count("Total net charge") == len(visited)
+    co = open(paths[2]).read()
+    assert co.count("Time = ") == len(visited) and co.count("  Production") == 2 * len(visited) and co.count("Tgas = ") == len(visited)
+    # a block is what write_contributions writes for that snapshot
+    buf = io.StringIO(); A.write_contributions(buf, net, touts[0], rec[0, :nS], G["ana_rates"], cell, sp)
+    assert co.split("\n", 1)[1].startswith(buf.getvalue())

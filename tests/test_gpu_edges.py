@@ -208,3 +208,34 @@ def test_multi_gpu_entry_point_with_one_device_is_the_single_device_call(racgpu,
             np.testing.assert_array_equal(multi["stats"][:, :8], one["stats"][:, :8])
     finally:
         m.close()
+
+
+def test_chem_analyse_on_the_engines_own_record(racgpu, setup, tmp_path):
+    """SURVEY 8(f) row 4 wired to the device output: the record and output times of racgpu_evol_solve_batch go through
+    analysis.chem_analyse (the reference's chem_analyse loop, src/disk.f90:4136-4300) with the engine's rate coefficients: the evol_ file
+    holds the record row for row, every visited record gets its elemental-residence block (net charge ~ 0, H residence fractions summing
+    to 1) and a production/destruction ranking whose leading terms are positive and sorted."""
+    net, y0 = setup
+    A = racgpu.analysis
+    cell = racgpu.cells.make_cell(50.0, 40.0, 1e8, 5.0, 1e3)[None, :]
+    p = racgpu.default_params(); p.t_max = 1e4
+    out = net.evol_solve_batch(p, cell, net.init_abundances(y0, cell), record=True)
+    nrr = int(out["stats"][0, racgpu.S_NREC_REAL]); nS = net.nSpecies
+    assert nrr > 100 and out["quality"][0] == 0
+    rates = net.cal_rates(p, cell)[0]
+    sp = [net.species_index("CO"), net.species_index("H2O"), net.species_index("E-")]
+    paths, visited = A.chem_analyse(net, str(tmp_path), 1, cell[0], out["touts"][0], out["record"][0], nrr, lambda T: rates, species=sp)
+    ev = open(paths[0]).read().splitlines()
+    assert len(ev) == nrr + 1
+    last = np.array([float(ev[nrr][14 * k:14 * (k + 1)]) for k in range(nS + 2)])
+    np.testing.assert_allclose(last[1:nS + 1], out["record"][0][nrr - 1, :nS], rtol=1.1e-4, atol=1e-300)
+    assert last[0] == pytest.approx(out["touts"][0][nrr - 1], rel=1e-4) and last[nS + 1] == pytest.approx(50.0)
+    assert 3 <= len(visited) <= 21 and visited[0] == 1
+    el = open(paths[1]).read()
+    assert el.count("Time = ") == len(visited)
+    charges = [float(l.split(":")[1]) for l in el.splitlines() if "Total net charge" in l]
+    assert max(abs(c) for c in charges) < 1e-12
+    co = open(paths[2]).read()
+    assert co.count("  Production") == 3 * len(visited) and co.count("  Destruction") == 3 * len(visited)
+    first = [l for l in co.splitlines() if l.startswith("       1")]
+    assert len(first) >= 2 * len(visited) and all(float(l[8:20]) >= 0.0 for l in first)
