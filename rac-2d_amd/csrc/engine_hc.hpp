@@ -94,7 +94,14 @@ constexpr unsigned kHcRowMask[10] = {
     HCM(HCB_CHEM) | HCM(HCB_PHD_H2O) | HCM(HCB_C_H2O),                                                                                                                           // H2O
     HCM(HCB_CHEM) | HCM(HCB_PHD_OH) | HCM(HCB_C_OH)};                                                                                                                            // OH
 #undef HCM
+#ifndef RG_HC_FENCES
+#define RG_HC_FENCES 1
+#endif
+#if RG_HC_FENCES
 #define HC_BLOCK() asm volatile("" ::: "memory")
+#else
+#define HC_BLOCK() do {} while (0)
+#endif
 RG_DEV double hc_tau2beta(double tau) { // tau2beta (src/sub_trivials.f90:1064-1085), factor 3
   if (tau <= 1e-4) return 1.0;
   const double tmp = 3.0 * tau;
