@@ -266,7 +266,7 @@ int racgpu_rectify_abundances(const racgpu_network *, int64_t ncell, double *y);
 /* The caller's sweep in dependency order, for grids whose cells form columns (reference: a cell is solved once the cells above
  * it are done, update_calculating_cells src/disk.f90:1937, because update_params_above_alt :1823-1883 puts integrals over their
  * end states into its record).  Column c holds cells col_cells[col_ptr[c] .. col_ptr[c+1]) from the surface downwards; every
- * column is solved top down by one team of four waves, columns side by side.  Before a cell is solved, the toISM self-shielding
+ * column is solved top down by one team of waves (eight; RG_TEAM), columns side by side.  Before a cell is solved, the toISM self-shielding
  * slots of its record are rewritten from the column densities N = sum n_gas X dz of the cells above it: H2 by
  * get_H2_self_shielding(N_H2, dv_turb) (:1887-1897), H2O and OH by exp(-N sigma_Lya) (:1847-1859), CO by get_12CO_shielding(N_H2,
  * N_CO) on the table given to racgpu_set_co_shielding_table (without one the CO slot stays as given), all capped at 1; the toStar
@@ -298,7 +298,7 @@ int racgpu_column_sweep(racgpu_network *, const racgpu_params *, int64_t ncolumn
  * The hint applies while ncell matches; cost == NULL or ncell == 0 clears it. */
 int racgpu_set_cost_hints(racgpu_network *, const double *cost, int64_t ncell);
 /* With cost hints in place, a cell whose expected cost exceeds frac x (sum of the costs / wave slots of the GPU) -- a cell that
- * would take that share of the pass's ideal length all by itself -- is solved by a team of four waves (at most one team per CU),
+ * would take that share of the pass's ideal length all by itself -- is solved by a team of eight waves (at most one team per CU),
  * started ahead of the rest.  Same arithmetic in the same order: results do not depend on it.  Default 0.5; frac <= 0: never.
  * Independently of hints, the cells still being integrated when the queue is empty and at most two waves per CU are left are handed
  * over to teams between two integrator steps (frac < 0 switches that off as well). */
