@@ -462,6 +462,47 @@ class Network:
                                               tos.ctypes.data if record else None, co.ctypes.data, F_RECTIFY if rectify else 0, MEM_HOST))
         return dict(y=y, t_final=tf, quality=q, stats=st, record=rec, touts=tos, cell_out=co, kernel_ms=lib().racgpu_last_kernel_ms(self._h))
 
+    def evolT_calc_cells(self, params, cell_records, hc_records, y, nlocal_iter=4):
+        """calc_this_cell's local-iteration loop (reference src/disk.f90:1651-1791) with the gas temperature co-evolving, driven from the host
+        on top of racgpu_evolT_solve_batch (racgpu_calc_cells is the fixed-T loop on the device side).  Iteration j = 2.. takes the cells
+        that ended flagged before half of their t_max and got past the previous iteration: abundances and Tgas of the hand-off record
+        (set_initial_condition_4solver_continue, :2100-2146), rectify_abundances, t0 = t_final, tolerance policy j; a cell whose T moved by
+        less than 1 % over the last iteration, with t_final >= 0.2 t_max and net heating below 1 % of its largest term
+        (heating_cooling_is_very_slow, src/heating_cooling.f90:1492-1498), goes on at fixed T (:1662-1667).  The reference applies that
+        last test to the terms of whichever heating_minus_cooling call came last; here they are evaluated at the hand-off state.
+        Returns dict(y, t_final, quality, tgas, niter [ncell], stats (summed work counters))."""
+        from . import cells as Cc
+        cr = np.array(cell_records, np.float64).reshape(-1, NPAR).copy()
+        n = cr.shape[0]
+        hr = np.array(hc_records, np.float64).reshape(n, NHC).copy()
+        y = np.array(y, np.float64).reshape(n, self.nSpecies).copy()
+        tmax = np.where(cr[:, Cc.P_TMAX] > 0.0, cr[:, Cc.P_TMAX], params.t_max)
+        tf = np.zeros(n); q = np.zeros(n, np.int32); niter = np.zeros(n, np.int32); st = np.zeros((n, NSTAT), np.int64)
+        act = np.arange(n)
+        for j in range(1, nlocal_iter + 1):
+            if act.size == 0:
+                break
+            T0 = cr[act, Cc.P_TGAS].copy()
+            o = self.evolT_solve_batch(params, cr[act], hr[act], y[act], t0=None if j == 1 else tf[act], tol_j=j, rectify=j > 1)
+            t_end = o["cell_out"][:, O_T_END]
+            proceeds = (j == 1) | (t_end > tf[act])               # "Local iteration does not proceed": nothing is taken over
+            useful = proceeds & (o["stats"][:, S_ISAV] > 1)
+            idx = act[useful]
+            y[idx] = o["y"][useful]; tf[idx] = o["t_final"][useful]; cr[idx, Cc.P_TGAS] = o["cell_out"][useful, O_TGAS]
+            q[act[proceeds]] = o["quality"][proceeds]; niter[act[proceeds]] = j
+            st[act, :8] += o["stats"][:, :8]
+            go = useful & (o["quality"] != 0) & (o["t_final"] < 0.5 * tmax[act])
+            nxt = act[go]
+            if nxt.size and j < nlocal_iter:                      # who goes on at fixed T (src/disk.f90:1662-1667)
+                yT = np.hstack([y[nxt], cr[nxt, Cc.P_TGAS][:, None]])
+                terms = self.ode_f_evolT(params, cr[nxt], hr[nxt], yT)["terms"]
+                slow = terms[:, 0] < 1e-2 * np.maximum(np.max(np.c_[terms[:, 1:12], -terms[:, 12]], axis=1), np.max(np.c_[terms[:, 12:29], -terms[:, 11]], axis=1))
+                same_T = np.abs(T0[go] - cr[nxt, Cc.P_TGAS]) <= 1e-2 * T0[go]
+                off = same_T & (tf[nxt] >= 0.2 * tmax[nxt]) & slow
+                hr[nxt[off], Cc.H_EN_GAIN_TOT] = 0.0
+            act = nxt
+        return dict(y=y, t_final=tf, quality=q, tgas=cr[:, Cc.P_TGAS].copy(), niter=niter, stats=st)
+
     def evolT_solve_batch_device(self, params, ncell, cells_ptr, hc_ptr, y_ptr, t_final_ptr=None, quality_ptr=None, stats_ptr=None, cell_out_ptr=None):
         _check(lib().racgpu_evolT_solve_batch(self._h, C.byref(params), ncell, cells_ptr, hc_ptr, y_ptr, None, None, t_final_ptr, quality_ptr,
                                               stats_ptr, None, None, cell_out_ptr, 0, MEM_DEVICE))

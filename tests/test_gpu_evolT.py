@@ -194,3 +194,33 @@ def test_four_waves_on_an_evolT_cell_give_the_bits_of_one(racgpu, ev):
     S = racgpu
     for col in (S.S_NST, S.S_NFE, S.S_NJE, S.S_NLU, S.S_NERR, S.S_QSUM, S.S_ERRCODES):
         np.testing.assert_array_equal(a["stats"][:, col], b["stats"][:, col])
+
+
+def test_local_iterations_with_T_evolving(racgpu, ev):
+    """Network.evolT_calc_cells: the caller's loop of calc_this_cell over racgpu_evolT_solve_batch.  With mxstep so small that every
+    interval returns ISTATE = -1, a cell ends flagged early and is continued from its hand-off record (abundances AND temperature) with the
+    next tolerance policy: each iteration gets further, the loop is the by-hand sequence of evolT_solve_batch calls bit for bit, and cells
+    that finish in the first iteration are what one evolT_solve_batch call returns."""
+    g, net = ev
+    p = racgpu.default_params()
+    cells = g["cells"][:4]; hc = g["hc"][:4]
+    y0 = net.init_abundances(g["y0"], cells)
+    full = net.evolT_calc_cells(p, cells, hc, y0, nlocal_iter=3)
+    one = net.evolT_solve_batch(p, cells, hc, y0, tol_j=1)
+    done = one["quality"] == 0
+    assert done.any()
+    np.testing.assert_array_equal(full["y"][done], one["y"][done])
+    np.testing.assert_array_equal(full["tgas"][done], one["cell_out"][done, racgpu.O_TGAS])
+    assert (full["niter"][done] == 1).all()
+    p.mxstep_per_interval = 6                                      # every interval ends in ISTATE = -1: flagged, stops early
+    loop = net.evolT_calc_cells(p, cells[:2], hc[:2], y0[:2], nlocal_iter=3)
+    assert (loop["niter"] >= 2).all()
+    # by hand for cell 0
+    C = racgpu.cells
+    c0 = cells[:1].copy(); h0 = hc[:1].copy(); yy = y0[:1].copy(); t = np.zeros(1)
+    for j in range(1, int(loop["niter"][0]) + 1):
+        o = net.evolT_solve_batch(p, c0, h0, yy, t0=None if j == 1 else t, tol_j=j, rectify=j > 1)
+        assert j == 1 or o["cell_out"][0, racgpu.O_T_END] > t[0]
+        yy = o["y"]; t = o["t_final"].copy(); c0[0, C.P_TGAS] = o["cell_out"][0, racgpu.O_TGAS]
+    np.testing.assert_array_equal(loop["y"][0], yy[0])
+    assert loop["t_final"][0] == t[0] and loop["tgas"][0] == c0[0, C.P_TGAS] and t[0] > 0.0
