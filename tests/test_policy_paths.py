@@ -144,6 +144,9 @@ def test_gpu_grid_cells_side_effects_and_tmax(racgpu):
         # n_mol_on_grain is a sum over the surface species of the end state: as close to the reference as the end state is
         np.testing.assert_allclose(out["cell_out"][k, racgpu.O_N_MOL_ON_GRAIN], G["grid_side"][k, 1], rtol=1e-3)
         assert out["cell_out"][k, racgpu.O_T_END] == out["t_final"][k]
+        # (RTOL 1e-4 end states: this fixture has no one-ulp twins; the per-cell bound max(1e-4, 3 x floor) is applied to 64 cells of the same
+        # grid with six twins each in tests/test_gpu_grid64.py.  Here: the loosest value the reference's own policy allows a cell whose
+        # integrator returned an error -- RTOL of the offending species raised to at most 1e-3 -- times three)
         assert major_relerr(out["y"][k], G["grid_yend"][k][:net.nSpecies]) <= 3e-3
     p8 = _params(racgpu, RTOL=1e-8)
     out = net.evol_solve_batch(p8, cells, net.init_abundances(G["y0"], cells))
