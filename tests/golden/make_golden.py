@@ -324,8 +324,9 @@ def main_grid64():
           % (np.median(fl), np.max(fl), np.median(tt), np.max(tt), out["scalars"][:, 2].sum(), out["scalars_ulp"][:, 2].sum(), out["scalars_tight"][:, 2].sum()))
 
 
-def main_evolT():
-    """tests/golden/evolT_grain.npz: gas temperature co-evolving with the chemistry (chemsol_params%evolT) on eight cells of the configs[2]
+def main_evolT(network="rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", initial="ini_abund_waterice_loMetal.dat", tag="evolT_grain",
+               idx=(20, 452, 3817, 8696, 11412, 14998, 15952, 19233)):
+    """tests/golden/evolT_grain.npz (and, with the README-default network and four of the cells, evolT_default.npz): gas temperature co-evolving with the chemistry (chemsol_params%evolT) on eight cells of the configs[2]
     grid with their heating/cooling records (cells.andrews_grid_hc): dy/dt incl. dT/dt and the 29 heating/cooling values at the
     initial state and at the end state, the finite-difference T row / T column of the Jacobian at the initial state, and the run
     itself: end state incl. T, T(t) of every record, whether the T-freeze test fired; the same with n_gas moved by one ulp (the
@@ -333,8 +334,7 @@ def main_evolT():
     C = importlib.import_module("rac-2d_amd.cells")
     grid, r, z = C.andrews_grid(return_geometry=True)
     hcg = C.andrews_grid_hc(grid, r, z)
-    network, initial = "rate06_dipole_reformated_again_withgrain_lowH2Bind.dat", "ini_abund_waterice_loMetal.dat"
-    idx = np.array([20, 452, 3817, 8696, 11412, 14998, 15952, 19233])
+    idx = np.array(idx)
     cells, hc = grid[idx], hcg[idx]
     cfg, meta = run_ref(network, initial, cells, 1e-4, 1e6, 50, 1, hc=hc)
     nS = len(meta["species"]); NEQ = nS + 1
@@ -384,7 +384,7 @@ def main_evolT():
                yend_tight=np.array([c["yend"] for c in tight]), scalars_tight=np.array([c["scalars"][:3] for c in tight]),
                Trecord_tight=pad([c["Trecord"] for c in tight]), evolTend_tight=np.array([c["evolTend"][0] for c in tight]),
                heat_rxn=meta["heat_rxn"], heat_val=meta["heat_val"], floor_twins=np.array(floors).T)
-    fn = os.path.join(HERE, "evolT_grain.npz")
+    fn = os.path.join(HERE, tag + ".npz")
     np.savez_compressed(fn, **out)
     for i in range(len(idx)):
         ye, yu, yt = out["yend"][i], out["yend_ulp"][i], out["yend_tight"][i]
@@ -472,6 +472,8 @@ if __name__ == "__main__":
         main_grid64()
     elif len(sys.argv) > 1 and sys.argv[1] == "evolT":
         main_evolT()
+    elif len(sys.argv) > 1 and sys.argv[1] == "evolT_default":
+        main_evolT("rate06_withgrain_lowH2Bind_hiOBind_lowCObind.dat", "ini_abund_waterice_loMetal_CO.dat", "evolT_default", (452, 8696, 14998, 19233))
     elif len(sys.argv) > 1 and sys.argv[1] == "moeq":
         main_moeq()
     elif len(sys.argv) > 1 and sys.argv[1] == "iterprobe":
