@@ -15,7 +15,7 @@ module racgpu
   public :: racgpu_network_load, racgpu_network_destroy, racgpu_network_dims, racgpu_species_name, &
             racgpu_species_index, racgpu_load_initial_abundances, racgpu_params_default, racgpu_n_record, &
             racgpu_set_tolerances, racgpu_init_abundances, racgpu_set_device, racgpu_device_count, &
-            racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_column_sweep, racgpu_set_co_shielding_table, racgpu_rectify_abundances, &
+            racgpu_solve_batch, racgpu_evol_solve_batch, racgpu_calc_cells, racgpu_column_sweep, racgpu_set_co_shielding_table, racgpu_set_star_rays, racgpu_star_ray_timeouts, racgpu_rectify_abundances, &
             racgpu_set_cost_hints, racgpu_set_team_threshold, racgpu_rates, racgpu_last_error, racgpu_last_kernel_ms
   public :: racgpu_error_string, chemsol_to_c, c_string
   ! gas temperature co-evolving with the chemistry (evolT) and the single-process multi-GPU entry points
@@ -242,6 +242,22 @@ module racgpu
       integer(c_int32_t), value :: nrow, ncol
       real(c_double), dimension(*), intent(in) :: logN_H2, logN_12CO, f
       integer(c_int) :: rc
+    end function
+    ! rays to the star for racgpu_column_sweep (calc_Ncol_to_Star, src/disk.f90:2543-2555, in the one-predecessor form of a column grid):
+    ! inner(cell) = the 0-based cell the ray from `cell` enters next (-1: none), ds(cell) = path length of such a ray through `cell` [cm];
+    ! with rays set the sweep also rewrites the toStar slots and a cell waits for inner(cell).  ncell = 0 or a null inner clears.
+    function racgpu_set_star_rays(h, ncell, inner, ds) bind(c, name='racgpu_set_star_rays') result(rc)
+      import :: c_ptr, c_int64_t, c_int32_t, c_double, c_int
+      type(c_ptr), value :: h
+      integer(c_int64_t), value :: ncell
+      integer(c_int32_t), dimension(*), intent(in) :: inner
+      real(c_double), dimension(*), intent(in) :: ds
+      integer(c_int) :: rc
+    end function
+    function racgpu_star_ray_timeouts(h) bind(c, name='racgpu_star_ray_timeouts') result(n)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int) :: n
     end function
     ! the sweep in dependency order for grids whose cells form columns (include/racgpu.h): columns top down, the toISM self-shielding
     ! slots of H2, H2O and OH rewritten on the device from the cells above; col_ptr/col_cells are 0-based
